@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the hybrid recall-search hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): 1M chunks x 3072-d fp32 PER GPU, top-k=10,
+full hybrid score (cosine + keyword + recency fused 0.7/0.2/0.1), candidate_limit =
+whole corpus.  A step is one pass of the hot path over one batch: every rank
+originates ONE query; with N ranks the corpus is N x 1M rows, row-sharded, and each
+query is scored against ALL shards (queries all-gathered, per-shard top-k' records
+all-gathered over RCCL, exact host finish).  Weak scaling: per-GPU rows are fixed,
+corpus and query count grow with N.  value = queries answered per second, whole job.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Inputs are resident in HBM before the timed region; results land in host memory
+inside it.  The oracle is used here ONLY for the `cpu_baseline` leg.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=3072)
+    ap.add_argument("--batch", type=int, default=1, help="queries originated per rank per step")
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=131072)
+    ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    return ap.parse_args()
+
+
+def build_shard(P, syn, torch, rank, rows, dim, n_total, dev):
+    idx = P.RecallIndex(dim=dim, device=dev.index or 0, capacity_rows=rows, row_base=rank * rows)
+    step = 32768
+    for r0 in range(0, rows, step):
+        m = min(step, rows - r0)
+        g0 = rank * rows + r0
+        pool, off = syn.contents(g0, m, dev)
+        idx.append(syn.embeddings(g0, m, dim, dev), syn.created_ticks(g0, m, n_total, dev), pool, off)
+    torch.cuda.synchronize()
+    idx.seal()
+    return idx
+
+
+def cpu_baseline(P, syn, args, n_total):
+    """The reference-faithful oracle (kind "port") timed on the host cores over a bounded sample."""
+    import numpy as np
+    from oracle import oracle_py as orc
+    m = min(args.cpu_sample_rows, args.rows_per_gpu)
+    nq = args.cpu_sample_queries
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    emb = syn.embeddings(0, m, args.dim).numpy()
+    created = syn.created_ticks(0, m, n_total).numpy()
+    pool, off = syn.contents(0, m)
+    corpus = orc.OracleCorpus(emb, created, (pool.numpy(), off.numpy()))
+    qs = syn.query_vectors(0, nq, args.dim, n_total).numpy()
+    texts = syn.query_texts(0, nq, n_total)
+    t0 = time.perf_counter()
+    for b in range(nq):
+        corpus.search(qs[b], texts[b], syn.NOW_TICKS, args.topk, candidate_limit=m, threads=cores)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    corpus.search(qs[0], texts[0], syn.NOW_TICKS, args.topk, candidate_limit=m, threads=1)
+    dt1 = time.perf_counter() - t1
+    rows_per_s = m * nq / dt
+    return {
+        "value": rows_per_s / args.rows_per_gpu, "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": f"{nq} queries x {m} of {args.rows_per_gpu} rows x {args.dim}-d scored by the C oracle "
+                  f"(reference arithmetic, full hybrid) on {cores} threads in {dt:.2f}s; "
+                  f"value = row-rate / rows per query (linear extrapolation)",
+        "single_thread_value": (m / dt1) / args.rows_per_gpu,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    P = graft.load_package()
+    syn = importlib.import_module(graft.PKG_NAME + ".synthetic")
+    sharded = importlib.import_module(graft.PKG_NAME + ".sharded")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows, dim, B_local, k = args.rows_per_gpu, args.dim, args.batch, args.topk
+    n_total = rows * world
+    idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev)
+    front = sharded.ShardedRecallSearch(idx, dim, dev) if world > 1 else None
+
+    n_steps_total = args.warmup + args.steps
+    # queries for every step, generated up front and resident in HBM (rank r originates queries
+    # r*B_local .. of each step's global batch)
+    q_steps, term_steps = [], []
+    for s in range(n_steps_total):
+        b0 = (s * world + rank) * B_local
+        q_steps.append(syn.query_vectors(b0, B_local, dim, n_total, dev))
+        term_steps.append([P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])
+    torch.cuda.synchronize()
+
+    def step(s):
+        if world > 1:
+            return front.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, n_total)
+        return idx.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
+
+    for s in range(args.warmup):
+        step(s)
+    idx.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for s in range(args.warmup, n_steps_total):
+        last = step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = idx.kernel_stats()
+    idx.set_profiling(False)
+
+    # sanity inside the bench: the planted row of the last step must be rank 1
+    planted = syn.planted_rows(((n_steps_total - 1) * world + rank) * B_local, B_local, n_total)
+    ok = [int(r) for r in last[0][:, 0]] == planted
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    if rank == 0:
+        queries = args.steps * world * B_local
+        dom = stats.get("dot_exact", {"launches": 0, "total_ms": 0.0, "algo_bytes": 0.0})
+        roofline = None
+        if dom["launches"]:
+            avg_ms = dom["total_ms"] / dom["launches"]
+            bytes_per_launch = dom["algo_bytes"] / dom["launches"]
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "dot_exact", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
+        out = {
+            "metric": "queries/sec at top-k=10 over N x 3072-d chunks",
+            "value": queries / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 products summed in f64 (reference arithmetic)",
+            "data": "synthetic",
+            "config": {"workload": f"C2: {rows} chunks x {dim}-d fp32 per GPU, {B_local} query per GPU per step, "
+                                   f"top-k={k}, full hybrid (cosine+keyword+recency), candidate_limit=corpus",
+                       "corpus_rows": n_total, "queries_per_step": world * B_local,
+                       "parallelism": f"row-sharded x{world}, all-gather of per-shard top-k'" if world > 1 else "single GPU"},
+            "row_scores_per_sec": queries * n_total / elapsed,
+            "rank1_is_planted_row": ok,
+            "roofline": roofline,
+            "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
+                        for n, v in stats.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, syn, args, n_total)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    idx.close()
+
+
+if __name__ == "__main__":
+    main()

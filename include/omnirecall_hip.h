@@ -1,0 +1,183 @@
+/*
+ * omnirecall_hip.h -- C ABI of libomnirecall_hip.so, the MI355X (gfx950) scorer
+ * behind the reference's IRecallSearchService seam.
+ *
+ * The reference has no FFI of its own: its only seam for this path is the DI
+ * interface
+ *     IRecallSearchService.SearchAsync(string query, int topK, CancellationToken)
+ *         src/OmniRecall.Api/Services/RecallSearchService.cs:6-9   (registered Program.cs:59)
+ * A drop-in GpuRecallSearchService keeps RecallSearchService.cs:22-25 (validate,
+ * embed) and :39-56 (file names, snippet, Math.Round, DTO) in C#, and replaces
+ * :26-37 -- GetRecentChunksAsync(300) + Select(ScoreChunk) + OrderByDescending /
+ * ThenByDescending / Take -- with ONE call into this library.  INTEGRATION.md
+ * shows the P/Invoke declarations that bind exactly these symbols.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types, no exceptions.
+ *   - every function returning int returns ORR_OK (0) or a negative orr_status;
+ *     orr_last_error() gives the thread-local message.  Numeric guard cases of
+ *     the reference (empty vector, dimension mismatch, zero norm;
+ *     RecallSearchService.cs:71-72,84-85) are NOT errors: they score cosine 0.
+ *   - the caller owns every buffer it passes; the library reads inputs only for
+ *     the duration of the call (append copies) and owns device memory behind
+ *     the opaque handle.  Strings cross as UTF-8 bytes with explicit offsets;
+ *     nothing relies on NUL termination; nothing is freed across the ABI.
+ *   - pointers marked "host or device" may be either; the library copies with
+ *     hipMemcpyDefault.
+ *   - threads: searches on a sealed index may be issued from any thread (they
+ *     are serialised per index in this version); append / seal are exclusive.
+ */
+#ifndef OMNIRECALL_HIP_H
+#define OMNIRECALL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORR_ABI_VERSION 1
+
+typedef enum orr_status {
+    ORR_OK      = 0,
+    ORR_EINVAL  = -1,   /* bad argument -> ArgumentException (RecallSearchService.cs:22-23)   */
+    ORR_ENOMEM  = -2,   /* host or device allocation failed                                   */
+    ORR_EDEVICE = -3,   /* HIP runtime / kernel failure, or no gfx950 device                   */
+    ORR_ECOMM   = -4,   /* shard exchange inconsistent (merge input malformed)                 */
+    ORR_EDIM    = -5,   /* appended embedding dimension differs from the index dimension       */
+    ORR_ESTATE  = -6    /* call not valid in this state (append after seal, search before)     */
+} orr_status;
+
+typedef struct orr_index orr_index;      /* opaque: one corpus shard resident on one GPU */
+
+typedef struct orr_config {
+    int32_t struct_size;      /* sizeof(orr_config), for forward compatibility                  */
+    int32_t device;           /* HIP device ordinal                                             */
+    int32_t dim;              /* embedding dimension D of every stored vector; 0 = corpus
+                                 without embeddings (NoOpEmbeddingClient.cs:7): cosine is 0     */
+    int32_t flags;            /* reserved, 0                                                    */
+    int64_t capacity_rows;    /* rows to reserve up front; 0 = grow on demand                   */
+    int64_t row_base;         /* position of this shard's first row in the GLOBAL
+                                 CreatedAt-descending candidate order (0 on a single GPU)       */
+} orr_config;
+
+/* One ranked-candidate record as exchanged between shards (56 bytes).  A shard
+ * emits kprime of these per query plus one trailer (see orr_search_shard). */
+typedef struct orr_candidate {
+    double  approx_score;   /* device-side fused score used for selection                      */
+    double  dot;            /* sum_i (double)fl32(q_i * e_i), reference order (…cs:77-82)      */
+    double  norm_b;         /* sum_i (double)fl32(e_i * e_i); 0 for rows without an embedding  */
+    int64_t created_ticks;  /* CosmosChunkRecord.CreatedAtUtc.Ticks                            */
+    int64_t row_id;         /* caller's id of the row (see orr_index_append); -1 = no record   */
+    int64_t order_key;      /* global candidate position (row_base + position in the shard)    */
+    int32_t matches;        /* query terms found in the content (…cs:111)                      */
+    int32_t flags;          /* ORR_CAND_* bits                                                 */
+    /* trailer record (index kprime of each query): approx_score = score of the
+     * worst kept candidate, or -inf when the shard kept every participating row;
+     * row_id = -1; order_key = rows that took part on this shard; matches =
+     * number of valid records in front of it; flags = ORR_CAND_TRAILER.       */
+} orr_candidate;
+
+#define ORR_CAND_TRAILER   1
+#define ORR_CAND_DOT_EXACT 2   /* `dot` is already the reference-order fp64 sum */
+
+/* Per-kernel timing collected with HIP events on the index's own stream. */
+typedef struct orr_kernel_stat {
+    char    name[48];
+    int64_t launches;
+    double  total_ms;        /* sum of hipEventElapsedTime over those launches                 */
+    double  algo_bytes;      /* algorithmic bytes summed over those launches       */
+} orr_kernel_stat;
+
+int         orr_abi_version(void);
+int         orr_device_count(void);                 /* gfx950 devices visible; 0 if none        */
+const char *orr_last_error(void);                   /* thread-local, never NULL                 */
+
+/* ---- corpus shard -------------------------------------------------------
+ * Replaces the data side of InMemoryIngestionStore.GetRecentChunksAsync
+ * (InMemoryIngestionStore.cs:57-65): rows are CosmosChunkRecord projections
+ * (Data/Models/CosmosIngestionRecords.cs:19-30). */
+int  orr_index_create(const orr_config *cfg, orr_index **out);
+void orr_index_destroy(orr_index *idx);
+
+/* Appends n rows in the store's enumeration order (copies; host or device
+ * pointers).
+ *   dim            == cfg.dim with emb = [n][dim] row-major fp32, or 0 with
+ *                  emb = NULL for rows whose Embedding is null/empty.  Any other
+ *                  dim is ORR_EDIM (a mixed-dimension corpus is not supported;
+ *                  in the reference such rows always score cosine 0 unless the
+ *                  query has that same odd dimension).
+ *   created_ticks  [n]    DateTime.Ticks of CreatedAtUtc.
+ *   content_lower  UTF-8 of Content.ToLowerInvariant() (RecallSearchService.cs:110
+ *                  is hoisted to ingest; the C# shim calls ToLowerInvariant itself).
+ *   content_off    [n+1]  byte offsets into content_lower.
+ *   row_ids        [n] ids returned by searches, or NULL for
+ *                  row_base + (rows appended so far) + i.                        */
+int orr_index_append(orr_index *idx, int64_t n, int32_t dim, const float *emb,
+                     const int64_t *created_ticks, const uint8_t *content_lower,
+                     const uint64_t *content_off, const int64_t *row_ids);
+
+/* Puts rows into candidate order -- stable CreatedAt-descending, i.e. what
+ * OrderByDescending(c => c.CreatedAtUtc) yields (InMemoryIngestionStore.cs:61) --
+ * and precomputes the exact row norms.  Required before searching. */
+int     orr_index_seal(orr_index *idx);
+int64_t orr_index_rows(const orr_index *idx);
+int32_t orr_index_dim(const orr_index *idx);
+
+/* ---- search -------------------------------------------------------------
+ * One batch of B queries against a sealed single-GPU index; replaces
+ * RecallSearchService.cs:26-37 for each query.
+ *   dim, q          query vectors [B][dim] (host or device); dim 0 = empty
+ *                   vector (EmbeddingResult.Vector = []), q may be NULL.
+ *   terms_utf8, term_off, query_term_off
+ *                   the queryTerms of RecallSearchService.cs:95-108, already split,
+ *                   lowercased, de-duplicated and stop-word filtered by the host:
+ *                   term t is terms_utf8[term_off[t] .. term_off[t+1]); query b owns
+ *                   terms query_term_off[b] .. query_term_off[b+1).  A query with no
+ *                   terms has keyword score 0 (:100-101).
+ *                   These three arrays are HOST memory.
+ *   now_ticks       the frozen DateTime.UtcNow.Ticks for :117.
+ *   topk            Take(Math.Max(1, topK)) (:36).
+ *   candidate_limit GetRecentChunksAsync(maxCount) (:26): 300 reproduces the
+ *                   reference, >= rows scores the whole corpus.
+ *   out_rows, out_scores  [B][max(1,topk)]: row ids and UNROUNDED fused scores in
+ *                   rank order (score desc, CreatedAt desc, candidate order).
+ *   out_counts      [B]: citations actually produced (< topk on a small corpus). */
+int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q,
+                     const uint8_t *terms_utf8, const uint32_t *term_off,
+                     const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+                     int64_t candidate_limit, int64_t *out_rows, double *out_scores,
+                     int32_t *out_counts);
+
+/* Row-sharded corpus, step 1 (runs on every shard's GPU): the shard's best
+ * kprime candidates per query, selected on (score desc, global candidate
+ * position asc).  out: [B][kprime+1] records (host or device), the last one of
+ * each query being the trailer.  candidate_limit is GLOBAL; the shard clips it
+ * with its row_base. */
+int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q,
+                     const uint8_t *terms_utf8, const uint32_t *term_off,
+                     const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
+                     int64_t candidate_limit, orr_candidate *out);
+
+/* Row-sharded corpus, step 2 (host only, no GPU needed): merges the gathered
+ * records of n_shards shards ([n_shards][B][kprime+1], host memory), rescoring
+ * every candidate in the reference's exact arithmetic and ranking with the exact
+ * key.  index_dim is the shards' embedding dimension (cosine applies only when
+ * dim == index_dim > 0, RecallSearchService.cs:71).  *out_uncertified (may be NULL) receives the number of queries whose
+ * top-k could not be certified against the shards' cut-off scores -- the caller
+ * should repeat both steps with a larger kprime for those. */
+int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all,
+                         int32_t index_dim, int32_t dim, const float *q_host,
+                         const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+                         int64_t *out_rows, double *out_scores, int32_t *out_counts,
+                         int32_t *out_uncertified);
+
+/* ---- measurement ---------------------------------------------------------*/
+int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets the counters */
+int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap);  /* returns count */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNIRECALL_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes bindings of the two in-tree shared libraries.
+
+  libomnirecall_hip.so   include/omnirecall_hip.h   (gfx950 scorer, the product)
+  libomnirecall_host.so  include/omnirecall_host.h  (host string semantics)
+
+There is no fallback: a missing library raises at import of this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG, "libomnirecall_hip.so")
+HOST_LIB_PATH = os.path.join(_PKG, "libomnirecall_host.so")
+
+
+class OrrError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libomnirecall_hip status {code}: {message}")
+        self.code = code
+
+
+ORR_OK, ORR_EINVAL, ORR_ENOMEM, ORR_EDEVICE, ORR_ECOMM, ORR_EDIM, ORR_ESTATE = 0, -1, -2, -3, -4, -5, -6
+ORR_CAND_TRAILER, ORR_CAND_DOT_EXACT = 1, 2
+
+
+class OrrConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32), ("flags", C.c_int32),
+                ("capacity_rows", C.c_int64), ("row_base", C.c_int64)]
+
+
+class OrrCandidate(C.Structure):
+    _fields_ = [("approx_score", C.c_double), ("dot", C.c_double), ("norm_b", C.c_double),
+                ("created_ticks", C.c_int64), ("row_id", C.c_int64), ("order_key", C.c_int64),
+                ("matches", C.c_int32), ("flags", C.c_int32)]
+
+
+class OrrKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("algo_bytes", C.c_double)]
+
+
+def _load(path: str) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                          "There is no CPU fallback for the scorer.")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip = _load(HIP_LIB_PATH)
+host = _load(HOST_LIB_PATH)
+
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+hip.orr_abi_version.restype = C.c_int
+hip.orr_device_count.restype = C.c_int
+hip.orr_last_error.restype = C.c_char_p
+hip.orr_index_create.restype = C.c_int
+hip.orr_index_create.argtypes = [C.POINTER(OrrConfig), C.POINTER(_vp)]
+hip.orr_index_destroy.restype = None
+hip.orr_index_destroy.argtypes = [_vp]
+hip.orr_index_append.restype = C.c_int
+hip.orr_index_append.argtypes = [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]
+hip.orr_index_seal.restype = C.c_int
+hip.orr_index_seal.argtypes = [_vp]
+hip.orr_index_rows.restype = _i64
+hip.orr_index_rows.argtypes = [_vp]
+hip.orr_index_dim.restype = _i32
+hip.orr_index_dim.argtypes = [_vp]
+hip.orr_search_batch.restype = C.c_int
+hip.orr_search_batch.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]
+hip.orr_search_shard.restype = C.c_int
+hip.orr_search_shard.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp]
+hip.orr_merge_candidates.restype = C.c_int
+hip.orr_merge_candidates.argtypes = [_i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]
+hip.orr_index_set_profiling.restype = C.c_int
+hip.orr_index_set_profiling.argtypes = [_vp, _i32]
+hip.orr_index_kernel_stats.restype = C.c_int
+hip.orr_index_kernel_stats.argtypes = [_vp, _vp, _i32]
+
+host.orrh_is_blank.restype = _i32
+host.orrh_is_blank.argtypes = [C.c_char_p, _i64]
+host.orrh_lower_invariant.restype = _i64
+host.orrh_lower_invariant.argtypes = [C.c_char_p, _i64, _vp, _i64]
+host.orrh_query_terms.restype = _i32
+host.orrh_query_terms.argtypes = [C.c_char_p, _i64, _vp, _i64, _vp, _i32]
+host.orrh_build_snippet.restype = _i64
+host.orrh_build_snippet.argtypes = [C.c_char_p, _i64, _i32, _vp, _i64]
+host.orrh_round4.restype = _dbl
+host.orrh_round4.argtypes = [_dbl]
+
+EXPORTED_HIP_SYMBOLS = [
+    "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",
+    "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
+    "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
+]
+EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
+                         "orrh_round4"]
+
+
+def check(status: int) -> None:
+    if status != ORR_OK:
+        raise OrrError(status, (hip.orr_last_error() or b"").decode("utf-8", "replace"))

@@ -1,0 +1,881 @@
+// orr_api.hip -- the C ABI of libomnirecall_hip.so (include/omnirecall_hip.h):
+// corpus shard management, search orchestration on the index's HIP stream, and
+// the host-side exact finish of the k' survivors.
+//
+// Replaces RecallSearchService.cs:26-37 (GetRecentChunksAsync + Select(ScoreChunk)
+// + OrderByDescending/ThenByDescending/Take) for a batch of queries.  There is NO
+// CPU scoring path here: without a gfx950 device every compute entry point
+// returns ORR_EDEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "orr_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(_e == hipErrorOutOfMemory ? ORR_ENOMEM : ORR_EDEVICE, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                            \
+    } while (0)
+
+#define ORR_TRY(expr)          \
+    do {                       \
+        int _r = (expr);       \
+        if (_r != ORR_OK) return _r; \
+    } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return ORR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(ORR_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return ORR_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct KernelStat {
+    std::string name;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+    double algo_bytes = 0.0;
+};
+
+struct PendingEvent {
+    int stat;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct orr_index {
+    int device = 0;
+    int32_t dim = 0;
+    int64_t row_base = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    // corpus, in append order until seal, in candidate order afterwards
+    int64_t n_rows = 0, cap_rows = 0;
+    float *d_emb = nullptr;
+    int64_t *d_created = nullptr;
+    int64_t *d_row_ids = nullptr;
+    uint64_t *d_off = nullptr;         // [cap_rows+1]
+    uint8_t *d_pool = nullptr;
+    uint64_t pool_len = 0, pool_cap = 0;
+    double *d_norm_b = nullptr;
+    std::vector<int64_t> h_created;    // host mirror (seal-time ordering, merge)
+    std::vector<uint64_t> h_off;       // host mirror of content offsets
+    bool sealed = false;
+
+    // search workspace
+    DevBuf ws_q, ws_dot, ws_matches, ws_sel, ws_cand, ws_qc, ws_terms, ws_term_pool, ws_qoff;
+    DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp;
+
+    // profiling
+    bool profiling = false;
+    std::vector<KernelStat> stats;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int stat_slot(orr_index *idx, const char *name)
+{
+    for (size_t i = 0; i < idx->stats.size(); ++i)
+        if (idx->stats[i].name == name) return (int)i;
+    KernelStat s;
+    s.name = name;
+    idx->stats.push_back(s);
+    return (int)idx->stats.size() - 1;
+}
+
+hipEvent_t take_event(orr_index *idx)
+{
+    if (!idx->event_pool.empty()) {
+        hipEvent_t e = idx->event_pool.back();
+        idx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Brackets one launch with events on the index's stream when profiling is on.
+struct Timed {
+    orr_index *idx;
+    PendingEvent pe;
+    bool on;
+    Timed(orr_index *i, const char *name, double algo_bytes) : idx(i), on(i->profiling)
+    {
+        if (!on) return;
+        pe.stat = stat_slot(idx, name);
+        idx->stats[pe.stat].algo_bytes += algo_bytes;
+        pe.start = take_event(idx);
+        pe.stop = take_event(idx);
+        (void)hipEventRecord(pe.start, idx->stream);
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        (void)hipEventRecord(pe.stop, idx->stream);
+        idx->pending.push_back(pe);
+    }
+};
+
+// After a stream synchronise: fold the finished event pairs into the counters.
+void collect_events(orr_index *idx)
+{
+    for (auto &pe : idx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+            idx->stats[pe.stat].launches += 1;
+            idx->stats[pe.stat].total_ms += (double)ms;
+        }
+        idx->event_pool.push_back(pe.start);
+        idx->event_pool.push_back(pe.stop);
+    }
+    idx->pending.clear();
+}
+
+int bind_device(const orr_index *idx)
+{
+    HIP_TRY(hipSetDevice(idx->device));
+    return ORR_OK;
+}
+
+template <typename T> int dev_alloc(T **out, size_t count)
+{
+    *out = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(out), count * sizeof(T));
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(ORR_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    return ORR_OK;
+}
+
+// Reallocates a device array keeping the first `keep` elements.
+template <typename T> int dev_grow(T **buf, size_t keep, size_t new_count, hipStream_t s)
+{
+    T *nb = nullptr;
+    ORR_TRY(dev_alloc(&nb, new_count));
+    if (*buf && keep) {
+        hipError_t e = hipMemcpyAsync(nb, *buf, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            (void)hipFree(nb);
+            return fail(ORR_EDEVICE, "device copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (*buf) (void)hipFree(*buf);
+    *buf = nb;
+    return ORR_OK;
+}
+
+int ensure_row_capacity(orr_index *idx, int64_t rows)
+{
+    if (rows <= idx->cap_rows) return ORR_OK;
+    int64_t nc = std::max<int64_t>(rows, idx->cap_rows + idx->cap_rows / 2);
+    nc = std::max<int64_t>(nc, 1024);
+    if (idx->dim > 0) ORR_TRY(dev_grow(&idx->d_emb, (size_t)idx->n_rows * idx->dim, (size_t)nc * idx->dim, idx->stream));
+    ORR_TRY(dev_grow(&idx->d_created, (size_t)idx->n_rows, (size_t)nc, idx->stream));
+    ORR_TRY(dev_grow(&idx->d_row_ids, (size_t)idx->n_rows, (size_t)nc, idx->stream));
+    ORR_TRY(dev_grow(&idx->d_off, (size_t)idx->n_rows + 1, (size_t)nc + 1, idx->stream));
+    idx->cap_rows = nc;
+    return ORR_OK;
+}
+
+int ensure_pool_capacity(orr_index *idx, uint64_t bytes)
+{
+    if (bytes + orr::kScanPoolSlack <= idx->pool_cap) return ORR_OK;
+    uint64_t nc = std::max<uint64_t>(bytes + orr::kScanPoolSlack, idx->pool_cap + idx->pool_cap / 2);
+    nc = std::max<uint64_t>(nc, 1u << 16);
+    ORR_TRY(dev_grow(&idx->d_pool, (size_t)idx->pool_len, (size_t)nc, idx->stream));
+    idx->pool_cap = nc;
+    return ORR_OK;
+}
+
+// Exact sum_i (double)fl32(q_i*q_i) in index order: normA of RecallSearchService.cs:80.
+double exact_norm(const float *q, int32_t dim)
+{
+    double acc = 0.0;
+    for (int32_t i = 0; i < dim; ++i) {
+        float p = q[i] * q[i];
+        acc += (double)p;
+    }
+    return acc;
+}
+
+// double.CompareTo
+int compare_double(double a, double b)
+{
+    if (a < b) return -1;
+    if (a > b) return 1;
+    if (a == b) return 0;
+    if (std::isnan(a)) return std::isnan(b) ? 0 : -1;
+    return 1;
+}
+
+struct Ranked {
+    double score;
+    int64_t order_key;
+    int64_t row_id;
+};
+
+// RecallSearchService.cs:59-67 for one surviving candidate, in the reference's own
+// arithmetic on the host (libm exp = what Math.Exp calls), from the exact pieces
+// the device produced.
+double exact_score(const orr_candidate &c, bool use_cos, double norm_a, int32_t n_terms, int64_t now_ticks)
+{
+    double cosv = 0.0;
+    if (use_cos) {
+        if (norm_a <= 0.0 || c.norm_b <= 0.0)
+            cosv = 0.0;
+        else
+            cosv = c.dot / (std::sqrt(norm_a) * std::sqrt(c.norm_b));
+    }
+    double kw = n_terms > 0 ? (double)c.matches / (double)n_terms : 0.0;
+    double total_days = (double)(now_ticks - c.created_ticks) / 864000000000.0;
+    double age_days = total_days > 0.0 ? total_days : 0.0;
+    double rec = std::exp(-age_days / 30.0);
+    return (cosv * 0.7) + (kw * 0.2) + (rec * 0.1);
+}
+
+// Absolute slack between the device's selection score and the exact host score
+// of the same row: identical IEEE operations except exp (ocml vs libm, a few ulp
+// of a value <= 1, times 0.1).
+constexpr double kCertifyEps = 1e-13;
+
+}  // namespace
+
+extern "C" {
+
+int orr_abi_version(void) { return ORR_ABI_VERSION; }
+
+const char *orr_last_error(void) { return g_last_error.c_str(); }
+
+int orr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int orr_index_create(const orr_config *cfg, orr_index **out)
+{
+    if (!cfg || !out) return fail(ORR_EINVAL, "orr_index_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(orr_config)) return fail(ORR_EINVAL, "orr_config.struct_size mismatch");
+    if (cfg->dim < 0 || cfg->capacity_rows < 0 || cfg->row_base < 0) return fail(ORR_EINVAL, "negative size in orr_config");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(ORR_EDEVICE, "no HIP device available: libomnirecall_hip has no CPU path");
+    if (cfg->device < 0 || cfg->device >= n_dev) return fail(ORR_EINVAL, "device %d out of range (%d visible)", cfg->device, n_dev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ORR_EDEVICE, "device %d is %s; this library carries gfx950 code only", cfg->device, prop.gcnArchName);
+    orr_index *idx = new (std::nothrow) orr_index();
+    if (!idx) return fail(ORR_ENOMEM, "out of host memory");
+    idx->device = cfg->device;
+    idx->dim = cfg->dim;
+    idx->row_base = cfg->row_base;
+    if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete idx;
+        return fail(ORR_EDEVICE, "cannot create a stream on device %d", cfg->device);
+    }
+    if (cfg->capacity_rows > 0) {
+        int r = ensure_row_capacity(idx, cfg->capacity_rows);
+        if (r != ORR_OK) { orr_index_destroy(idx); return r; }
+    }
+    *out = idx;
+    return ORR_OK;
+}
+
+void orr_index_destroy(orr_index *idx)
+{
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    for (auto &pe : idx->pending) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
+    for (auto e : idx->event_pool) (void)hipEventDestroy(e);
+    if (idx->d_emb) (void)hipFree(idx->d_emb);
+    if (idx->d_created) (void)hipFree(idx->d_created);
+    if (idx->d_row_ids) (void)hipFree(idx->d_row_ids);
+    if (idx->d_off) (void)hipFree(idx->d_off);
+    if (idx->d_pool) (void)hipFree(idx->d_pool);
+    if (idx->d_norm_b) (void)hipFree(idx->d_norm_b);
+    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_matches, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc,
+                      &idx->ws_terms, &idx->ws_term_pool, &idx->ws_qoff, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp};
+    for (auto b : bufs) b->release();
+    if (idx->stream) (void)hipStreamDestroy(idx->stream);
+    delete idx;
+}
+
+int64_t orr_index_rows(const orr_index *idx) { return idx ? idx->n_rows : 0; }
+int32_t orr_index_dim(const orr_index *idx) { return idx ? idx->dim : 0; }
+
+int orr_index_append(orr_index *idx, int64_t n, int32_t dim, const float *emb, const int64_t *created_ticks,
+                     const uint8_t *content_lower, const uint64_t *content_off, const int64_t *row_ids)
+{
+    if (!idx) return fail(ORR_EINVAL, "orr_index_append: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (idx->sealed) return fail(ORR_ESTATE, "orr_index_append: index is sealed");
+    if (n < 0) return fail(ORR_EINVAL, "orr_index_append: negative row count");
+    if (n == 0) return ORR_OK;
+    if (!created_ticks || !content_off) return fail(ORR_EINVAL, "orr_index_append: created_ticks and content_off are required");
+    if (dim != 0 && dim != idx->dim)
+        return fail(ORR_EDIM, "orr_index_append: dim %d differs from the index dimension %d", dim, idx->dim);
+    if (dim != 0 && !emb) return fail(ORR_EINVAL, "orr_index_append: emb is NULL with dim %d", dim);
+    if (idx->n_rows + n >= (int64_t)0xFFFFFFFFll) return fail(ORR_EINVAL, "orr_index_append: more than 2^32-1 rows in one shard");
+    ORR_TRY(bind_device(idx));
+    ORR_TRY(ensure_row_capacity(idx, idx->n_rows + n));
+
+    // content offsets: bring to the host, rebase onto the pool
+    std::vector<uint64_t> off((size_t)n + 1);
+    HIP_TRY(hipMemcpy(off.data(), content_off, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyDefault));
+    for (int64_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return fail(ORR_EINVAL, "orr_index_append: content_off is not monotone at row %lld", (long long)i);
+    const uint64_t bytes = off[n] - off[0];
+    if (bytes > 0 && !content_lower) return fail(ORR_EINVAL, "orr_index_append: content_lower is NULL");
+    ORR_TRY(ensure_pool_capacity(idx, idx->pool_len + bytes));
+    if (bytes > 0)
+        HIP_TRY(hipMemcpyAsync(idx->d_pool + idx->pool_len, content_lower + off[0], bytes, hipMemcpyDefault, idx->stream));
+    if (idx->h_off.empty()) idx->h_off.push_back(0);
+    for (int64_t i = 0; i < n; ++i) idx->h_off.push_back(idx->pool_len + (off[i + 1] - off[0]));
+    HIP_TRY(hipMemcpyAsync(idx->d_off + idx->n_rows, idx->h_off.data() + idx->n_rows, sizeof(uint64_t) * ((size_t)n + 1),
+                           hipMemcpyHostToDevice, idx->stream));
+    idx->pool_len += bytes;
+
+    // timestamps (host mirror + device)
+    const size_t old = idx->h_created.size();
+    idx->h_created.resize(old + (size_t)n);
+    HIP_TRY(hipMemcpy(idx->h_created.data() + old, created_ticks, sizeof(int64_t) * (size_t)n, hipMemcpyDefault));
+    HIP_TRY(hipMemcpyAsync(idx->d_created + idx->n_rows, idx->h_created.data() + old, sizeof(int64_t) * (size_t)n,
+                           hipMemcpyHostToDevice, idx->stream));
+
+    // embeddings: copy, or zero rows (a zero row has normB = 0 -> cosine 0, the same
+    // value the null/empty guard of RecallSearchService.cs:71 yields)
+    if (idx->dim > 0) {
+        float *dst = idx->d_emb + (size_t)idx->n_rows * idx->dim;
+        const size_t eb = sizeof(float) * (size_t)n * idx->dim;
+        if (dim == idx->dim)
+            HIP_TRY(hipMemcpyAsync(dst, emb, eb, hipMemcpyDefault, idx->stream));
+        else
+            HIP_TRY(hipMemsetAsync(dst, 0, eb, idx->stream));
+    }
+    if (row_ids)
+        HIP_TRY(hipMemcpyAsync(idx->d_row_ids + idx->n_rows, row_ids, sizeof(int64_t) * (size_t)n, hipMemcpyDefault, idx->stream));
+    else
+        HIP_TRY(orr::launch_iota_i64(idx->d_row_ids + idx->n_rows, n, idx->row_base + idx->n_rows, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->n_rows += n;
+    return ORR_OK;
+}
+
+int orr_index_seal(orr_index *idx)
+{
+    if (!idx) return fail(ORR_EINVAL, "orr_index_seal: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (idx->sealed) return ORR_OK;
+    ORR_TRY(bind_device(idx));
+    const int64_t n = idx->n_rows;
+
+    // candidate order: stable sort by CreatedAt descending (InMemoryIngestionStore.cs:61)
+    std::vector<int64_t> perm((size_t)n);
+    std::iota(perm.begin(), perm.end(), (int64_t)0);
+    const int64_t *cr = idx->h_created.data();
+    bool identity = true;
+    for (int64_t i = 1; i < n && identity; ++i) identity = cr[i - 1] >= cr[i];
+    if (!identity) {
+        std::stable_sort(perm.begin(), perm.end(), [cr](int64_t a, int64_t b) { return cr[a] > cr[b]; });
+        int64_t *d_perm = nullptr;
+        ORR_TRY(dev_alloc(&d_perm, (size_t)n));
+        HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, idx->stream));
+        if (idx->dim > 0) {
+            float *ne = nullptr;
+            ORR_TRY(dev_alloc(&ne, (size_t)idx->cap_rows * idx->dim));
+            HIP_TRY(orr::launch_gather_rows_f32(idx->d_emb, ne, d_perm, n, idx->dim, idx->stream));
+            HIP_TRY(hipStreamSynchronize(idx->stream));
+            (void)hipFree(idx->d_emb);
+            idx->d_emb = ne;
+        }
+        int64_t *nc = nullptr, *nr = nullptr;
+        ORR_TRY(dev_alloc(&nc, (size_t)idx->cap_rows));
+        ORR_TRY(dev_alloc(&nr, (size_t)idx->cap_rows));
+        HIP_TRY(orr::launch_gather_i64(idx->d_created, nc, d_perm, n, idx->stream));
+        HIP_TRY(orr::launch_gather_i64(idx->d_row_ids, nr, d_perm, n, idx->stream));
+        std::vector<uint64_t> noff((size_t)n + 1);
+        noff[0] = 0;
+        for (int64_t p = 0; p < n; ++p) noff[p + 1] = noff[p] + (idx->h_off[perm[p] + 1] - idx->h_off[perm[p]]);
+        uint64_t *d_noff = nullptr;
+        uint8_t *npool = nullptr;
+        ORR_TRY(dev_alloc(&d_noff, (size_t)idx->cap_rows + 1));
+        ORR_TRY(dev_alloc(&npool, (size_t)idx->pool_cap));
+        HIP_TRY(hipMemcpyAsync(d_noff, noff.data(), sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, idx->stream));
+        HIP_TRY(orr::launch_gather_content(idx->d_pool, idx->d_off, npool, d_noff, d_perm, n, idx->stream));
+        HIP_TRY(hipStreamSynchronize(idx->stream));
+        (void)hipFree(idx->d_created); idx->d_created = nc;
+        (void)hipFree(idx->d_row_ids); idx->d_row_ids = nr;
+        (void)hipFree(idx->d_off); idx->d_off = d_noff;
+        (void)hipFree(idx->d_pool); idx->d_pool = npool;
+        (void)hipFree(d_perm);
+        std::vector<int64_t> sorted_created((size_t)n);
+        for (int64_t p = 0; p < n; ++p) sorted_created[p] = cr[perm[p]];
+        idx->h_created.swap(sorted_created);
+        idx->h_off.swap(noff);
+    }
+
+    // K0: exact row norms, sum_i (double)fl32(e_i*e_i) (RecallSearchService.cs:81)
+    ORR_TRY(dev_alloc(&idx->d_norm_b, (size_t)std::max<int64_t>(n, 1)));
+    if (idx->dim > 0 && n > 0) {
+        Timed t(idx, "row_norms_exact", 4.0 * (double)n * idx->dim + 8.0 * (double)n);
+        HIP_TRY(orr::launch_dot_exact(idx->d_emb, n, idx->dim, nullptr, 1, true, idx->d_norm_b, n, idx->stream));
+    } else if (n > 0) {
+        HIP_TRY(hipMemsetAsync(idx->d_norm_b, 0, sizeof(double) * (size_t)n, idx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    collect_events(idx);
+    idx->sealed = true;
+    return ORR_OK;
+}
+
+int orr_index_set_profiling(orr_index *idx, int32_t enabled)
+{
+    if (!idx) return fail(ORR_EINVAL, "null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->profiling = enabled != 0;
+    idx->stats.clear();
+    return ORR_OK;
+}
+
+int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap)
+{
+    if (!idx) return fail(ORR_EINVAL, "null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const int32_t n = (int32_t)idx->stats.size();
+    for (int32_t i = 0; i < n && i < cap && out; ++i) {
+        memset(&out[i], 0, sizeof(orr_kernel_stat));
+        strncpy(out[i].name, idx->stats[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = idx->stats[i].launches;
+        out[i].total_ms = idx->stats[i].total_ms;
+        out[i].algo_bytes = idx->stats[i].algo_bytes;
+    }
+    return n;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct BatchArgs {
+    int32_t B, dim;
+    const float *q;
+    const uint8_t *terms_utf8;
+    const uint32_t *term_off;
+    const uint32_t *query_term_off;
+    int64_t now_ticks;
+    int64_t candidate_limit;
+};
+
+int check_batch(const orr_index *idx, const BatchArgs &a, const char *fn)
+{
+    if (!idx) return fail(ORR_EINVAL, "%s: null index", fn);
+    if (!idx->sealed) return fail(ORR_ESTATE, "%s: index is not sealed", fn);
+    if (a.B <= 0) return fail(ORR_EINVAL, "%s: batch size must be positive", fn);
+    if (a.dim < 0) return fail(ORR_EINVAL, "%s: negative query dimension", fn);
+    if (a.dim > 0 && !a.q) return fail(ORR_EINVAL, "%s: q is NULL with dim %d", fn, a.dim);
+    if (!a.query_term_off) return fail(ORR_EINVAL, "%s: query_term_off is required", fn);
+    return ORR_OK;
+}
+
+// Rows of this shard that take part: the global candidate prefix clipped to the shard.
+int64_t participating_rows(const orr_index *idx, int64_t candidate_limit)
+{
+    const int64_t limit = std::max<int64_t>(1, candidate_limit);     // Take(Math.Max(1, maxCount))
+    const int64_t local = limit - idx->row_base;
+    return std::max<int64_t>(0, std::min<int64_t>(local, idx->n_rows));
+}
+
+// Device side of one batch: exact dots, keyword matches, fused scores, selection.
+// Leaves [B][kprime+1] records in idx->ws_cand.  Caller holds the lock.
+int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, std::vector<float> *q_host_out)
+{
+    ORR_TRY(bind_device(idx));
+    const int64_t n = participating_rows(idx, a.candidate_limit);
+    const int32_t B = a.B;
+    const bool use_cos = a.dim > 0 && a.dim == idx->dim;
+    hipStream_t s = idx->stream;
+
+    // queries
+    std::vector<float> q_host;
+    if (a.dim > 0) {
+        q_host.resize((size_t)B * a.dim);
+        HIP_TRY(hipMemcpy(q_host.data(), a.q, sizeof(float) * q_host.size(), hipMemcpyDefault));
+    }
+    std::vector<uint32_t> qoff((size_t)B + 1);
+    memcpy(qoff.data(), a.query_term_off, sizeof(uint32_t) * ((size_t)B + 1));
+    for (int32_t b = 0; b < B; ++b)
+        if (qoff[b + 1] < qoff[b]) return fail(ORR_EINVAL, "query_term_off is not monotone at query %d", b);
+    const uint32_t t_begin = qoff[0], t_end = qoff[B];
+    const uint32_t n_terms_total = t_end - t_begin;
+    if (n_terms_total > 0 && (!a.term_off || !a.terms_utf8)) return fail(ORR_EINVAL, "terms are referenced but term_off/terms_utf8 is NULL");
+
+    std::vector<orr::QueryConst> qc((size_t)B);
+    for (int32_t b = 0; b < B; ++b) {
+        qc[b].use_cos = use_cos ? 1 : 0;
+        qc[b].norm_a = use_cos ? exact_norm(q_host.data() + (size_t)b * a.dim, a.dim) : 0.0;
+        qc[b].n_terms = (int32_t)(qoff[b + 1] - qoff[b]);
+        if (qc[b].n_terms > 65535) return fail(ORR_EINVAL, "query %d has more than 65535 terms", b);
+    }
+    ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
+    HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc.data(), sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
+
+    ORR_TRY(idx->ws_cand.reserve(sizeof(orr_candidate) * (size_t)B * ((size_t)kprime + 1)));
+    orr_candidate *d_cand = idx->ws_cand.as<orr_candidate>();
+
+    if (n == 0) {   // nothing on this shard takes part: empty records + trailers
+        std::vector<orr_candidate> empty((size_t)B * ((size_t)kprime + 1));
+        for (auto &c : empty) { memset(&c, 0, sizeof(c)); c.row_id = -1; c.order_key = -1; }
+        for (int32_t b = 0; b < B; ++b) {
+            orr_candidate &t = empty[(size_t)b * (kprime + 1) + kprime];
+            t.approx_score = -std::numeric_limits<double>::infinity();
+            t.order_key = 0; t.matches = 0; t.flags = ORR_CAND_TRAILER;
+        }
+        HIP_TRY(hipMemcpyAsync(d_cand, empty.data(), sizeof(orr_candidate) * empty.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (q_host_out) q_host_out->swap(q_host);
+        return ORR_OK;
+    }
+
+    // K1e exact dots, kMaxExactQ queries per launch
+    double *d_dot = nullptr;
+    if (use_cos) {
+        ORR_TRY(idx->ws_q.reserve(sizeof(float) * (size_t)B * a.dim));
+        ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
+        HIP_TRY(hipMemcpyAsync(idx->ws_q.p, q_host.data(), sizeof(float) * q_host.size(), hipMemcpyHostToDevice, s));
+        d_dot = idx->ws_dot.as<double>();
+        for (int32_t b0 = 0; b0 < B; b0 += orr::kMaxExactQ) {
+            const int32_t nq = std::min<int32_t>(orr::kMaxExactQ, B - b0);
+            Timed t(idx, "dot_exact", 4.0 * (double)n * idx->dim + 4.0 * nq * idx->dim + 8.0 * nq * (double)n);
+            HIP_TRY(orr::launch_dot_exact(idx->d_emb, n, idx->dim, idx->ws_q.as<float>() + (size_t)b0 * a.dim, nq, false,
+                                          d_dot + (size_t)b0 * n, n, s));
+        }
+    }
+
+    // K3 keyword scan
+    uint16_t *d_matches = nullptr;
+    if (n_terms_total > 0) {
+        ORR_TRY(idx->ws_matches.reserve(sizeof(uint16_t) * (size_t)B * (size_t)n));
+        d_matches = idx->ws_matches.as<uint16_t>();
+        std::vector<orr::ScanTerm> st(n_terms_total);
+        const uint32_t pool0 = a.term_off[t_begin];
+        const uint32_t pool_bytes = a.term_off[t_end] - pool0;
+        for (uint32_t t = 0; t < n_terms_total; ++t) {
+            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
+            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
+            st[t].off = o - pool0;
+            st[t].len = e - o;
+            uint32_t pre = 0, msk = 0;
+            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
+                pre |= (uint32_t)a.terms_utf8[o + k] << (8 * k);
+                msk |= 0xFFu << (8 * k);
+            }
+            st[t].prefix = pre;
+            st[t].mask = msk;
+        }
+        ORR_TRY(idx->ws_terms.reserve(sizeof(orr::ScanTerm) * st.size()));
+        ORR_TRY(idx->ws_term_pool.reserve((size_t)pool_bytes + 16));
+        ORR_TRY(idx->ws_qoff.reserve(sizeof(uint32_t) * ((size_t)B + 1 + n_terms_total)));
+        HIP_TRY(hipMemcpyAsync(idx->ws_terms.p, st.data(), sizeof(orr::ScanTerm) * st.size(), hipMemcpyHostToDevice, s));
+        if (pool_bytes)
+            HIP_TRY(hipMemcpyAsync(idx->ws_term_pool.p, a.terms_utf8 + pool0, pool_bytes, hipMemcpyHostToDevice, s));
+        // launches: groups of queries whose terms fit kMaxScanTerms; a query with more
+        // terms than that is scanned alone in slices, accumulating.
+        std::vector<uint32_t> rel;   // per-launch relative query_term_off arrays, packed
+        struct Launch { int32_t b0, nb; uint32_t t0, nt; size_t rel_at; int acc; };
+        std::vector<Launch> launches;
+        int32_t b = 0;
+        while (b < B) {
+            const uint32_t tq = qoff[b + 1] - qoff[b];
+            if (tq > (uint32_t)orr::kMaxScanTerms) {
+                for (uint32_t o = 0; o < tq; o += orr::kMaxScanTerms) {
+                    const uint32_t nt = std::min<uint32_t>(orr::kMaxScanTerms, tq - o);
+                    Launch L{b, 1, qoff[b] - t_begin + o, nt, rel.size(), o > 0};
+                    rel.push_back(0); rel.push_back(nt);
+                    launches.push_back(L);
+                }
+                ++b;
+                continue;
+            }
+            int32_t e = b;
+            uint32_t nt = 0;
+            while (e < B && e - b < 64 && (qoff[e + 1] - qoff[e]) <= (uint32_t)orr::kMaxScanTerms &&
+                   nt + (qoff[e + 1] - qoff[e]) <= (uint32_t)orr::kMaxScanTerms) {
+                nt += qoff[e + 1] - qoff[e];
+                ++e;
+            }
+            Launch L{b, e - b, qoff[b] - t_begin, nt, rel.size(), 0};
+            for (int32_t i = b; i <= e; ++i) rel.push_back(qoff[i] - qoff[b]);
+            launches.push_back(L);
+            b = e;
+        }
+        ORR_TRY(idx->ws_qoff.reserve(sizeof(uint32_t) * rel.size()));
+        HIP_TRY(hipMemcpyAsync(idx->ws_qoff.p, rel.data(), sizeof(uint32_t) * rel.size(), hipMemcpyHostToDevice, s));
+        const double content_bytes = (double)(idx->h_off[n] - idx->h_off[0]);
+        for (const auto &L : launches) {
+            Timed t(idx, "keyword_scan", content_bytes + 8.0 * (double)(n + 1) + 2.0 * L.nb * (double)n);
+            HIP_TRY(orr::launch_keyword_scan(idx->d_pool, idx->d_off, n, idx->ws_term_pool.as<uint8_t>(),
+                                             idx->ws_terms.as<orr::ScanTerm>() + L.t0, (int32_t)L.nt,
+                                             idx->ws_qoff.as<uint32_t>() + L.rel_at, L.nb,
+                                             d_matches + (size_t)L.b0 * n, n, L.acc, s));
+        }
+    }
+
+    // K4/K5 fused score + selection
+    if (kprime <= orr::kSelWidth) {
+        const int64_t n_seg = (n + orr::kSelSegRows - 1) / orr::kSelSegRows;
+        ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)n_seg * orr::kSelWidth));
+        {
+            Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0 + 2.0));
+            HIP_TRY(orr::launch_fuse_select(d_dot, n, idx->d_norm_b, idx->d_created, d_matches, n,
+                                            idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B,
+                                            idx->ws_sel.as<orr::SelEntry>(), s));
+        }
+        {
+            Timed t(idx, "select_final", (double)B * (double)n_seg * orr::kSelWidth * sizeof(orr::SelEntry));
+            HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), (int32_t)n_seg, B, kprime, n, idx->row_base,
+                                             d_dot, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, d_matches, n, 1,
+                                             d_cand, s));
+        }
+    } else {
+        // generic large-k path: full stable sort of every score, query by query
+        ORR_TRY(idx->ws_keys_a.reserve(sizeof(unsigned long long) * (size_t)n));
+        ORR_TRY(idx->ws_keys_b.reserve(sizeof(unsigned long long) * (size_t)n));
+        ORR_TRY(idx->ws_vals_a.reserve(sizeof(uint32_t) * (size_t)n));
+        ORR_TRY(idx->ws_vals_b.reserve(sizeof(uint32_t) * (size_t)n));
+        size_t tmp_bytes = 0;
+        HIP_TRY(orr::sort_pairs_desc(nullptr, tmp_bytes, idx->ws_keys_a.as<unsigned long long>(),
+                                     idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(),
+                                     idx->ws_vals_b.as<uint32_t>(), n, s));
+        ORR_TRY(idx->ws_sort_tmp.reserve(tmp_bytes));
+        for (int32_t b = 0; b < B; ++b) {
+            const double *dq = d_dot ? d_dot + (size_t)b * n : nullptr;
+            const uint16_t *mq = d_matches ? d_matches + (size_t)b * n : nullptr;
+            {
+                Timed t(idx, "score_keys", (double)n * 38.0);
+                HIP_TRY(orr::launch_score_keys(dq, idx->d_norm_b, idx->d_created, mq, qc[b], a.now_ticks, n,
+                                               idx->ws_keys_a.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(), s));
+            }
+            {
+                Timed t(idx, "radix_sort_desc", (double)n * 12.0 * 2.0 * 8.0);
+                size_t tb = idx->ws_sort_tmp.cap;
+                HIP_TRY(orr::sort_pairs_desc(idx->ws_sort_tmp.p, tb, idx->ws_keys_a.as<unsigned long long>(),
+                                             idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(),
+                                             idx->ws_vals_b.as<uint32_t>(), n, s));
+            }
+            HIP_TRY(orr::launch_records_from_sorted(idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_b.as<uint32_t>(),
+                                                    kprime, n, idx->row_base, dq, idx->d_norm_b, idx->d_created,
+                                                    idx->d_row_ids, mq, 1, d_cand + (size_t)b * (kprime + 1), s));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    collect_events(idx);
+    if (q_host_out) q_host_out->swap(q_host);
+    return ORR_OK;
+}
+
+// Host finish for one query over records from any number of shards.
+// Returns the number of results; *certified tells whether rows outside the
+// candidate sets were provably unable to reach the top-k.
+int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, int32_t kprime, bool use_cos,
+                     double norm_a, int32_t n_terms, int64_t now_ticks, int32_t topk, int64_t *out_rows,
+                     double *out_scores, bool *certified, int *err)
+{
+    std::vector<Ranked> ranked;
+    double cutoff = -std::numeric_limits<double>::infinity();
+    bool any_cut = false;
+    *err = ORR_OK;
+    for (int32_t sidx = 0; sidx < n_shards; ++sidx) {
+        const orr_candidate *rec = shard_recs[sidx];
+        const orr_candidate &tr = rec[kprime];
+        if (!(tr.flags & ORR_CAND_TRAILER) || tr.matches < 0 || tr.matches > kprime) {
+            *err = fail(ORR_ECOMM, "orr_merge_candidates: shard %d has a malformed trailer", sidx);
+            return 0;
+        }
+        for (int32_t i = 0; i < tr.matches; ++i) {
+            const orr_candidate &c = rec[i];
+            if (c.row_id < 0 && c.order_key < 0) continue;
+            Ranked r;
+            r.score = exact_score(c, use_cos, norm_a, n_terms, now_ticks);
+            r.order_key = c.order_key;
+            r.row_id = c.row_id;
+            ranked.push_back(r);
+        }
+        if (tr.approx_score != -std::numeric_limits<double>::infinity()) {
+            any_cut = true;
+            // NaN cut-off: everything left out is NaN too (NaN sorts last), harmless
+            if (!(tr.approx_score != tr.approx_score) && tr.approx_score > cutoff) cutoff = tr.approx_score;
+        }
+    }
+    std::sort(ranked.begin(), ranked.end(), [](const Ranked &x, const Ranked &y) {
+        const int c = compare_double(x.score, y.score);
+        if (c != 0) return c > 0;                 // OrderByDescending(score)       :34
+        return x.order_key < y.order_key;         // ThenByDescending(created), stable == candidate order  :35
+    });
+    const int32_t take = std::max<int32_t>(1, topk);                                 // :36
+    const int32_t n_out = (int32_t)std::min<size_t>((size_t)take, ranked.size());
+    for (int32_t i = 0; i < n_out; ++i) {
+        out_rows[i] = ranked[i].row_id;
+        out_scores[i] = ranked[i].score;
+    }
+    if (!any_cut) {
+        *certified = true;
+    } else if (n_out < take) {
+        *certified = false;                       // fewer results than asked while rows were cut
+    } else {
+        const double sk = ranked[n_out - 1].score;
+        *certified = sk > cutoff + kCertifyEps;   // false for NaN
+    }
+    return n_out;
+}
+
+int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all, int32_t dim, bool use_cos,
+               const float *q_host, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+               int64_t *out_rows, double *out_scores, int32_t *out_counts, int32_t *out_uncertified)
+{
+    const int32_t take = std::max<int32_t>(1, topk);
+    int32_t unc = 0;
+    std::vector<const orr_candidate *> recs((size_t)n_shards);
+    for (int32_t b = 0; b < B; ++b) {
+        for (int32_t sidx = 0; sidx < n_shards; ++sidx)
+            recs[sidx] = all + ((size_t)sidx * B + b) * ((size_t)kprime + 1);
+        const double norm_a = use_cos ? exact_norm(q_host + (size_t)b * dim, dim) : 0.0;
+        const int32_t n_terms = (int32_t)(query_term_off[b + 1] - query_term_off[b]);
+        bool cert = false;
+        int err = ORR_OK;
+        for (int32_t i = 0; i < take; ++i) { out_rows[(size_t)b * take + i] = -1; out_scores[(size_t)b * take + i] = 0.0; }
+        const int32_t cnt = finish_query(recs.data(), n_shards, kprime, use_cos, norm_a, n_terms, now_ticks, topk,
+                                         out_rows + (size_t)b * take, out_scores + (size_t)b * take, &cert, &err);
+        if (err != ORR_OK) return err;
+        if (out_counts) out_counts[b] = cnt;
+        if (!cert) ++unc;
+    }
+    if (out_uncertified) *out_uncertified = unc;
+    return ORR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
+                     const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
+                     int64_t candidate_limit, orr_candidate *out)
+{
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
+    ORR_TRY(check_batch(idx, a, "orr_search_shard"));
+    if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
+    if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    ORR_TRY(run_shard(idx, a, kprime, nullptr));
+    HIP_TRY(hipMemcpy(out, idx->ws_cand.p, sizeof(orr_candidate) * (size_t)B * ((size_t)kprime + 1), hipMemcpyDefault));
+    return ORR_OK;
+}
+
+int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all, int32_t index_dim,
+                         int32_t dim, const float *q_host, const uint32_t *query_term_off, int64_t now_ticks,
+                         int32_t topk, int64_t *out_rows, double *out_scores, int32_t *out_counts,
+                         int32_t *out_uncertified)
+{
+    if (n_shards < 1 || B < 1 || kprime < 1) return fail(ORR_EINVAL, "orr_merge_candidates: sizes must be positive");
+    if (!all || !query_term_off || !out_rows || !out_scores) return fail(ORR_EINVAL, "orr_merge_candidates: null argument");
+    if (dim < 0 || index_dim < 0) return fail(ORR_EINVAL, "orr_merge_candidates: negative dimension");
+    const bool use_cos = dim > 0 && dim == index_dim;
+    if (use_cos && !q_host) return fail(ORR_EINVAL, "orr_merge_candidates: q_host is required with dim %d", dim);
+    return merge_impl(n_shards, B, kprime, all, dim, use_cos, q_host, query_term_off, now_ticks, topk, out_rows,
+                      out_scores, out_counts, out_uncertified);
+}
+
+int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
+                     const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+                     int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_counts)
+{
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
+    ORR_TRY(check_batch(idx, a, "orr_search_batch"));
+    if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_search_batch: output buffers are required");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const int32_t take = std::max<int32_t>(1, topk);
+    const int64_t n = participating_rows(idx, candidate_limit);
+    const bool use_cos = dim > 0 && dim == idx->dim;
+
+    // k': the asked k plus a margin, escalated until every query certifies.
+    int64_t kprime = std::min<int64_t>(std::max<int64_t>(1, n), std::max<int64_t>((int64_t)take + 22, 32));
+    if (kprime > orr::kSelWidth && take + 8 <= orr::kSelWidth) kprime = orr::kSelWidth;
+    for (;;) {
+        std::vector<float> q_host;
+        ORR_TRY(run_shard(idx, a, (int32_t)kprime, &q_host));
+        std::vector<orr_candidate> recs((size_t)B * ((size_t)kprime + 1));
+        HIP_TRY(hipMemcpy(recs.data(), idx->ws_cand.p, sizeof(orr_candidate) * recs.size(), hipMemcpyDeviceToHost));
+        int32_t unc = 0;
+        ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs.data(), dim, use_cos, q_host.data(), query_term_off, now_ticks,
+                           topk, out_rows, out_scores, out_counts, &unc));
+        if (unc == 0 || kprime >= n) return ORR_OK;
+        kprime = std::min<int64_t>(n, kprime * 4);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// orr_kernels.h -- launch wrappers of the gfx950 kernels behind libomnirecall_hip.so.
+// All launches are asynchronous on the given stream; none allocates or synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/omnirecall_hip.h"
+
+namespace orr {
+
+constexpr int kSelWidth = 64;        // entries a wave keeps while selecting (one per lane)
+constexpr int kSelSegRows = 4096;    // rows one workgroup of fuse_select scans
+constexpr int kMaxExactQ = 4;        // queries one launch of the exact dot kernel carries
+constexpr int kMaxScanTerms = 64;    // query terms one launch of the keyword scan carries
+
+// One selection entry: `key` orders scores (see score_key in the .hip), `pos` is the
+// row's position in the shard's candidate order.  key 0 = empty slot.
+struct SelEntry {
+    unsigned long long key;
+    uint32_t pos;
+    uint32_t pad;
+};
+
+// Per-term metadata for the keyword scan (built on the host per batch).
+struct ScanTerm {
+    uint32_t off;      // byte offset of the term in the term pool
+    uint32_t len;      // bytes
+    uint32_t prefix;   // first min(4,len) bytes, little-endian packed
+    uint32_t mask;     // byte mask of those bytes
+};
+
+// K0 / K1e: out[q][r] = sum_i (double)fl32(Q[q][i] * E[r][i]) in index order (exact
+// reference arithmetic, RecallSearchService.cs:77-82).  self_norm: Q is ignored and
+// out[0][r] = sum_i (double)fl32(E[r][i]^2).  nq <= kMaxExactQ.
+hipError_t launch_dot_exact(const float *E, int64_t n_rows, int32_t D, const float *Q, int32_t nq,
+                            bool self_norm, double *out, int64_t out_stride, hipStream_t s);
+
+// K3: matches[b][r] = number of terms of query b that occur in row r's content
+// (RecallSearchService.cs:111).  n_terms <= kMaxScanTerms; q_term_off[B+1] indexes
+// into terms[0..n_terms).  accumulate != 0 adds to matches instead of overwriting (a
+// query with more than kMaxScanTerms terms is scanned in several launches).  The pool
+// must be over-allocated by kScanPoolSlack bytes.
+constexpr size_t kScanPoolSlack = 2048;
+hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *off, int64_t n_rows,
+                               const uint8_t *term_pool, const ScanTerm *terms, int32_t n_terms,
+                               const uint32_t *q_term_off, int32_t B, uint16_t *matches,
+                               int64_t matches_stride, int32_t accumulate, hipStream_t s);
+
+// Per-query constants of the fused score.
+struct QueryConst {
+    double norm_a;        // exact sum_i (double)fl32(q_i^2); unused when use_cos == 0
+    int32_t n_terms;      // queryTerms.Length (RecallSearchService.cs:112)
+    int32_t use_cos;      // query dim == index dim and dim > 0
+};
+
+// K4+K5a: fused score per (query,row) and per-workgroup top-64.
+//   score = (cos*0.7) + (kw*0.2) + (rec*0.1)  in fp64, left to right (…cs:66)
+// out_sel: [B][n_seg][kSelWidth] entries, best first.  n_seg = ceil(n_rows / kSelSegRows).
+hipError_t launch_fuse_select(const double *dot, int64_t dot_stride, const double *norm_b,
+                              const int64_t *created, const uint16_t *matches, int64_t matches_stride,
+                              const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
+                              SelEntry *out_sel, hipStream_t s);
+
+// K5b: merges the per-workgroup lists of each query and writes kprime candidate
+// records plus the trailer ([B][kprime+1], see orr_candidate).
+hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, int32_t kprime,
+                               int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
+                               const double *norm_b, const int64_t *created, const int64_t *row_ids,
+                               const uint16_t *matches, int64_t matches_stride, int32_t dot_exact,
+                               orr_candidate *out, hipStream_t s);
+
+// Generic path for large k: keys[r] = score key of (query b,row r), vals[r] = r.
+hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,
+                             const uint16_t *matches, QueryConst qc, int64_t now_ticks, int64_t n_rows,
+                             unsigned long long *keys, uint32_t *vals, hipStream_t s);
+// Device radix sort (descending, stable) of (keys, vals); temp sizing by query.
+hipError_t sort_pairs_desc(void *temp, size_t &temp_bytes, const unsigned long long *keys_in,
+                           unsigned long long *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                           int64_t n, hipStream_t s);
+// Builds candidate records for the first K sorted entries (+ trailer at index K).
+hipError_t launch_records_from_sorted(const unsigned long long *keys, const uint32_t *vals, int32_t K,
+                                      int64_t n_rows, int64_t row_base, const double *dot,
+                                      const double *norm_b, const int64_t *created, const int64_t *row_ids,
+                                      const uint16_t *matches, int32_t dot_exact, orr_candidate *out,
+                                      hipStream_t s);
+
+// Seal-time row permutation (dst[p] = src[perm[p]]).
+hipError_t launch_gather_rows_f32(const float *src, float *dst, const int64_t *perm, int64_t n, int32_t D,
+                                  hipStream_t s);
+hipError_t launch_gather_i64(const int64_t *src, int64_t *dst, const int64_t *perm, int64_t n, hipStream_t s);
+hipError_t launch_gather_content(const uint8_t *src_pool, const uint64_t *src_off, uint8_t *dst_pool,
+                                 const uint64_t *dst_off, const int64_t *perm, int64_t n, hipStream_t s);
+hipError_t launch_iota_i64(int64_t *dst, int64_t n, int64_t base, hipStream_t s);
+
+}  // namespace orr

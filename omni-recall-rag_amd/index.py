@@ -1,0 +1,167 @@
+"""RecallIndex: a thin Python handle over the C ABI (include/omnirecall_hip.h),
+used by the tests, bench.py and the sharded front-end.  It adds no arithmetic:
+every score comes out of libomnirecall_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+CAND_DTYPE = np.dtype([("approx_score", "<f8"), ("dot", "<f8"), ("norm_b", "<f8"), ("created_ticks", "<i8"),
+                       ("row_id", "<i8"), ("order_key", "<i8"), ("matches", "<i4"), ("flags", "<i4")])
+assert CAND_DTYPE.itemsize == C.sizeof(N.OrrCandidate) == 56
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x) -> Optional[int]:
+    """Raw address of a numpy array or torch tensor (host or device)."""
+    if x is None:
+        return None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr()
+    assert x.flags["C_CONTIGUOUS"]
+    return x.ctypes.data
+
+
+def pack_terms(queries_terms: Sequence[Sequence[bytes]]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """[[term bytes]] per query -> (terms_utf8, term_off, query_term_off) of the ABI."""
+    pool = bytearray()
+    term_off = [0]
+    qoff = [0]
+    for terms in queries_terms:
+        for t in terms:
+            pool += bytes(t)
+            term_off.append(len(pool))
+        qoff.append(len(term_off) - 1)
+    pool_arr = np.frombuffer(bytes(pool) + b"\0", dtype=np.uint8).copy()
+    return pool_arr, np.asarray(term_off, dtype=np.uint32), np.asarray(qoff, dtype=np.uint32)
+
+
+def pack_contents(contents: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(contents) + 1, dtype=np.uint64)
+    if len(contents):
+        off[1:] = np.cumsum([len(c) for c in contents], dtype=np.uint64)
+    pool = np.frombuffer(b"".join(bytes(c) for c in contents) + b"\0", dtype=np.uint8).copy()
+    return pool, off
+
+
+class RecallIndex:
+    """One corpus shard resident on one GPU (orr_index)."""
+
+    def __init__(self, dim: int, device: int = 0, capacity_rows: int = 0, row_base: int = 0):
+        cfg = N.OrrConfig(C.sizeof(N.OrrConfig), device, dim, 0, capacity_rows, row_base)
+        h = C.c_void_p()
+        N.check(N.hip.orr_index_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.dim = dim
+        self.row_base = row_base
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            N.hip.orr_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def rows(self) -> int:
+        return int(N.hip.orr_index_rows(self._h))
+
+    def append(self, emb, created_ticks, content_lower, content_off=None, row_ids=None) -> None:
+        """emb: [n, dim] float32 (numpy or torch, host or device) or None for rows without an
+        embedding; created_ticks: [n] int64; content_lower: list of lowercased bytes, or a uint8
+        pool with content_off [n+1] uint64 (numpy or torch)."""
+        if content_off is None:
+            content_lower, content_off = pack_contents(content_lower)
+        n = int(content_off.shape[0]) - 1
+        if not _is_torch(created_ticks):
+            created_ticks = np.ascontiguousarray(created_ticks, dtype=np.int64)
+        if emb is not None and not _is_torch(emb):
+            emb = np.ascontiguousarray(emb, dtype=np.float32)
+        if row_ids is not None and not _is_torch(row_ids):
+            row_ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        dim = 0 if emb is None else int(emb.shape[1])
+        N.check(N.hip.orr_index_append(self._h, n, dim, _ptr(emb), _ptr(created_ticks), _ptr(content_lower),
+                                       _ptr(content_off), _ptr(row_ids)))
+
+    def seal(self) -> None:
+        N.check(N.hip.orr_index_seal(self._h))
+
+    @staticmethod
+    def _query_args(qvecs, n_queries: int):
+        if qvecs is None:
+            return 0, None, None
+        if not _is_torch(qvecs):
+            qvecs = np.ascontiguousarray(qvecs, dtype=np.float32).reshape(n_queries, -1)
+        dim = int(qvecs.shape[1])
+        return dim, (qvecs if dim > 0 else None), qvecs
+
+    def search(self, qvecs, queries_terms: Sequence[Sequence[bytes]], now_ticks: int, topk: int,
+               candidate_limit: int = 300):
+        """orr_search_batch.  Returns (rows [B,k] int64, scores [B,k] float64, counts [B] int32)."""
+        B = len(queries_terms)
+        dim, q, _keep = self._query_args(qvecs, B)
+        pool, toff, qoff = pack_terms(queries_terms)
+        k = max(1, int(topk))
+        rows = np.full((B, k), -1, dtype=np.int64)
+        scores = np.zeros((B, k), dtype=np.float64)
+        counts = np.zeros(B, dtype=np.int32)
+        N.check(N.hip.orr_search_batch(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks,
+                                       int(topk), int(candidate_limit), _ptr(rows), _ptr(scores), _ptr(counts)))
+        return rows, scores, counts
+
+    def search_shard(self, qvecs, queries_terms, now_ticks: int, kprime: int, candidate_limit: int, out=None):
+        """orr_search_shard.  Returns a [B, kprime+1] structured array (or fills `out`, which may be a
+        torch uint8 tensor on the device with B*(kprime+1)*56 bytes)."""
+        B = len(queries_terms)
+        dim, q, _keep = self._query_args(qvecs, B)
+        pool, toff, qoff = pack_terms(queries_terms)
+        if out is None:
+            out = np.zeros((B, kprime + 1), dtype=CAND_DTYPE)
+        N.check(N.hip.orr_search_shard(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks,
+                                       int(kprime), int(candidate_limit), _ptr(out)))
+        return out
+
+    def set_profiling(self, on: bool) -> None:
+        N.check(N.hip.orr_index_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_stats(self) -> dict:
+        arr = (N.OrrKernelStat * 32)()
+        n = N.hip.orr_index_kernel_stats(self._h, C.cast(arr, C.c_void_p), 32)
+        return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms),
+                                       "algo_bytes": float(arr[i].algo_bytes)} for i in range(min(n, 32))}
+
+
+def merge_candidates(all_records: np.ndarray, index_dim: int, qvecs, queries_terms, now_ticks: int, topk: int):
+    """orr_merge_candidates over [n_shards, B, kprime+1] records (host).  Returns
+    (rows, scores, counts, uncertified)."""
+    assert all_records.dtype == CAND_DTYPE and all_records.ndim == 3
+    n_shards, B, kp1 = all_records.shape
+    all_records = np.ascontiguousarray(all_records)
+    if qvecs is None:
+        dim, q = 0, None
+    else:
+        q = np.ascontiguousarray(qvecs, dtype=np.float32).reshape(B, -1)
+        dim = int(q.shape[1])
+        q = q if dim > 0 else None
+    _, _, qoff = pack_terms(queries_terms)
+    k = max(1, int(topk))
+    rows = np.full((B, k), -1, dtype=np.int64)
+    scores = np.zeros((B, k), dtype=np.float64)
+    counts = np.zeros(B, dtype=np.int32)
+    unc = C.c_int32(0)
+    N.check(N.hip.orr_merge_candidates(n_shards, B, kp1 - 1, _ptr(all_records), index_dim, dim, _ptr(q), _ptr(qoff),
+                                       now_ticks, int(topk), _ptr(rows), _ptr(scores), _ptr(counts),
+                                       C.cast(C.byref(unc), C.c_void_p)))
+    return rows, scores, counts, int(unc.value)

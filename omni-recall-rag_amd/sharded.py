@@ -1,0 +1,107 @@
+"""Row-sharded search across the GPUs of one node: one process per GPU, the corpus
+split into contiguous ranges of the global candidate order.
+
+Per step:  all-gather the queries (every rank may originate some)  ->  every rank
+scores ALL queries against its own shard (orr_search_shard, HBM-bound: the shard is
+read once for the whole batch)  ->  ONE all-gather of the per-shard candidate
+records over RCCL/xGMI  ->  every rank finishes the queries on the host
+(orr_merge_candidates) and keeps the ones it originated.  No all-reduce anywhere.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .index import CAND_DTYPE, RecallIndex, merge_candidates
+
+TERM_SLOT = 256        # bytes reserved per query for its packed terms
+
+
+def _pack_terms_fixed(terms: Sequence[bytes]) -> np.ndarray:
+    out = bytearray([len(terms)])
+    for t in terms:
+        if len(t) > 255:
+            raise ValueError("term longer than 255 bytes")
+        out.append(len(t))
+        out += t
+    if len(out) > TERM_SLOT or len(terms) > 255:
+        raise ValueError("query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
+    out += bytes(TERM_SLOT - len(out))
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def _unpack_terms_fixed(slot: np.ndarray) -> List[bytes]:
+    n, p, out = int(slot[0]), 1, []
+    for _ in range(n):
+        ln = int(slot[p])
+        out.append(bytes(slot[p + 1:p + 1 + ln]))
+        p += 1 + ln
+    return out
+
+
+class ShardedRecallSearch:
+    """`index` is this rank's shard (row_base = its first global row).  `device` is the
+    torch device of this rank, or "cpu" for gloo rehearsals with a stub shard search."""
+
+    def __init__(self, index, index_dim: int, device, group=None, shard_search=None):
+        self.index = index
+        self.index_dim = index_dim
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit) -> records [B,kprime+1]
+        self._shard_search = shard_search or (lambda q, t, now, kp, lim, out=None:
+                                              self.index.search_shard(q, t, now, kp, lim, out=out))
+
+    def search(self, q_local: torch.Tensor, terms_local: Sequence[Sequence[bytes]], now_ticks: int, topk: int,
+               candidate_limit: int, kprime: int = 32):
+        """q_local: [B_local, dim] float32 on self.device (dim may be 0).  Every rank must call with
+        the same B_local, dim, now_ticks, topk, candidate_limit.  Returns this rank's
+        (rows [B_local,k], scores [B_local,k], counts [B_local])."""
+        B_local = len(terms_local)
+        dim = int(q_local.shape[1]) if q_local is not None and q_local.numel() else 0
+        W = self.world
+        # ---- exchange 1: queries (vector bytes + packed terms in one buffer per query)
+        vec_bytes = 4 * dim
+        slot = vec_bytes + TERM_SLOT
+        send = torch.empty((B_local, slot), dtype=torch.uint8, device=self.device)
+        if dim:
+            send[:, :vec_bytes] = q_local.contiguous().view(torch.uint8).reshape(B_local, vec_bytes)
+        tslots = np.stack([_pack_terms_fixed(t) for t in terms_local])
+        send[:, vec_bytes:] = torch.from_numpy(tslots).to(self.device, non_blocking=True)
+        if W > 1:
+            allq = torch.empty((W * B_local, slot), dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(allq, send, group=self.group)
+        else:
+            allq = send
+        B = W * B_local
+        q_all = allq[:, :vec_bytes].contiguous().view(torch.float32).reshape(B, dim) if dim else None
+        tall = allq[:, vec_bytes:].cpu().numpy()
+        terms_all = [_unpack_terms_fixed(tall[b]) for b in range(B)]
+
+        while True:
+            # ---- local scoring of every query against this shard
+            rec_bytes = B * (kprime + 1) * CAND_DTYPE.itemsize
+            mine = torch.empty(rec_bytes, dtype=torch.uint8, device=self.device)
+            self._shard_search(q_all, terms_all, now_ticks, kprime, candidate_limit, out=mine)
+            # ---- exchange 2: ONE all-gather of the per-shard top-k' records
+            if W > 1:
+                allrec = torch.empty(W * rec_bytes, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(allrec, mine, group=self.group)
+            else:
+                allrec = mine
+            recs = allrec.cpu().numpy().view(CAND_DTYPE).reshape(W, B, kprime + 1)
+            # Every rank finishes EVERY query from the same gathered bytes, so all ranks reach the
+            # same "escalate or not" decision without another collective.
+            q_host = q_all.cpu().numpy() if dim else None
+            rows, scores, counts, unc = merge_candidates(recs, self.index_dim, q_host, terms_all, now_ticks, topk)
+            lo = self.rank * B_local
+            rows, scores, counts = rows[lo:lo + B_local], scores[lo:lo + B_local], counts[lo:lo + B_local]
+            total = int(recs[:, 0, kprime]["order_key"].sum())
+            if unc == 0 or kprime >= total:
+                return rows, scores, counts
+            kprime = min(max(total, 1), kprime * 4)

@@ -1,0 +1,223 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same inputs.  Bar: identical row ids in identical order, fp64 scores
+bit-identical (the survivors are finished in the reference's own arithmetic)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import DAY, NOW, assert_same_ranking, build_index, oracle_corpus, orc, pkg, random_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _kat_corpus(seed):
+    chunks = seed["chunks"]
+    dim = max((len(c["embedding"]) for c in chunks if c["embedding"]), default=0)
+    return {"emb": [None if not c["embedding"] else np.asarray(c["embedding"], np.float32) for c in chunks],
+            "created": np.asarray([c["createdTicks"] for c in chunks], dtype=np.int64),
+            "contents": [c["content"] for c in chunks], "dim": dim}
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_reference_known_answers_through_the_c_abi(kats, i):
+    case = kats["cases"][i]
+    c = _kat_corpus(case["seed"])
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    qv = case["queryVector"] or None
+    rows, scores = assert_same_ranking(idx, corpus, c, qv, case["query"], case["topK"], 300, now=kats["nowTicks"])
+    chunks = case["seed"]["chunks"]
+    files = {d["id"]: d["fileName"] for d in case["seed"]["documents"]}
+    a = case["asserted"]
+    if "rank1DocumentId" in a:
+        assert chunks[rows[0]]["documentId"] == a["rank1DocumentId"]
+    if "rank1FileName" in a:
+        assert files[chunks[rows[0]]["documentId"]] == a["rank1FileName"]
+    assert [chunks[r]["documentId"] for r in rows] == case["derivedOrder"]
+    for r, s in zip(rows, scores):
+        want = case.get("derivedScores", {}).get(chunks[r]["documentId"])
+        if want is not None:
+            assert s == want
+    idx.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3, 64, 768, 3072])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 700])
+def test_exact_dot_and_norm_kernels(dim, n):
+    """K0/K1e against the oracle's sequential fp64 sums, read back through the candidate records."""
+    P = pkg()
+    rng = np.random.default_rng(dim * 1000 + n)
+    emb = (rng.standard_normal((n, dim)) * rng.choice([1.0, 1e-3, 50.0], size=(n, 1))).astype(np.float32)
+    created = (NOW - np.arange(n, dtype=np.int64) * 1000)
+    idx = P.RecallIndex(dim=dim)
+    idx.append(emb, created, [b"x"] * n)
+    idx.seal()
+    B = 3
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    kp = min(n, 64)
+    rec = idx.search_shard(qs, [[b"x"]] * B, NOW, kp, n)
+    for b in range(B):
+        tr = rec[b, kp]
+        assert tr["flags"] == P.native.ORR_CAND_TRAILER and tr["matches"] == kp and tr["order_key"] == n
+        for c in rec[b, :kp]:
+            r = int(c["row_id"])
+            assert c["dot"] == orc.dot(qs[b], emb[r])
+            assert c["norm_b"] == orc.dot(emb[r], emb[r])
+            assert c["matches"] == 1 and c["created_ticks"] == created[r] and c["order_key"] == r
+    idx.close()
+
+
+QUERY_TEXTS = ["alpha", "the kubernetes helm", "what is the", "GAMMA delta zzz", "net ab abcdefghij", "Été naïve",
+               "q? x1 db", "abcd abcde abc", "kubernetes " * 3 + "Deployment yaml chart azure cosmos vector search"]
+
+
+@pytest.mark.parametrize("seed,n,dim", [(1, 50, 2), (2, 300, 3), (3, 1500, 64), (4, 4200, 128), (5, 9000, 768)])
+def test_search_matches_oracle_on_mixed_corpora(seed, n, dim):
+    """Unsorted appends (seal permutes), null embeddings, duplicates (exact ties),
+    future timestamps, empty contents; topK and candidate_limit edge values."""
+    rng = np.random.default_rng(seed)
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c, chunk=977)
+    corpus = oracle_corpus(c)
+    qvecs = [rng.standard_normal(dim).astype(np.float32), None, np.zeros(dim, np.float32),
+             rng.standard_normal(dim + 1).astype(np.float32)]            # last: dimension mismatch -> cosine 0
+    some_row = next(r for r in range(n) if c["emb"][r] is not None)
+    qvecs.append(c["emb"][some_row].copy())                               # cosine 1 on that row and its duplicates
+    for qi, qv in enumerate(qvecs):
+        for ti in (qi, qi + 4):
+            text = QUERY_TEXTS[ti % len(QUERY_TEXTS)]
+            for topk, limit in ((10, n), (1, 300), (-1, n), (0, 1), (3, 2), (40, n), (n + 5, n), (64, 300)):
+                assert_same_ranking(idx, corpus, c, qv, text, topk, limit)
+    idx.close()
+
+
+def test_nan_and_inf_embeddings_rank_like_double_compareto():
+    rng = np.random.default_rng(7)
+    c = random_corpus(rng, 400, 64, p_null=0.0)
+    c["emb"][5][3] = np.nan
+    c["emb"][77][0] = np.inf
+    c["emb"][200][:] = 0.0
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    q = rng.standard_normal(64).astype(np.float32)
+    for topk in (10, 400, 405):
+        assert_same_ranking(idx, corpus, c, q, "alpha beta", topk, 400)
+    qn = q.copy()
+    qn[1] = np.nan
+    assert_same_ranking(idx, corpus, c, qn, "alpha", 12, 400)
+    idx.close()
+
+
+def test_corpus_without_embeddings_is_keyword_and_recency_only():
+    """Default configuration of the reference: NoOpEmbeddingClient, cosine 0 everywhere (F7)."""
+    rng = np.random.default_rng(8)
+    c = random_corpus(rng, 2500, 0)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    for text in QUERY_TEXTS[:5]:
+        for topk, limit in ((5, 300), (10, 2500), (70, 2500)):
+            assert_same_ranking(idx, corpus, c, None, text, topk, limit)
+    idx.close()
+
+
+def test_massive_ties_fall_back_to_candidate_order():
+    """Every row identical: the top-k is the first k rows in candidate order (F4)."""
+    n, dim = 5000, 64
+    e = np.ones(dim, np.float32)
+    c = {"emb": [e.copy() for _ in range(n)], "created": np.full(n, NOW - DAY, np.int64),
+         "contents": ["alpha beta"] * n, "dim": dim}
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    rows, _ = assert_same_ranking(idx, corpus, c, e, "alpha", 10, n)
+    assert list(rows) == list(range(10))
+    assert_same_ranking(idx, corpus, c, None, "zzz", 100, n)
+    idx.close()
+
+
+def test_long_contents_and_many_terms():
+    """Contents longer than one 1 KiB scan step, matches that straddle step boundaries,
+    terms of 1..12 bytes, and a query with more than 64 terms (sliced launches)."""
+    rng = np.random.default_rng(12)
+    n = 300
+    contents = []
+    for r in range(n):
+        k = int(rng.integers(100, 600))
+        words = list(rng.choice(["lorem", "ipsum", "dolor", "sit", "amet", "consectetur", "adipiscing", "elit"], size=k))
+        if r % 3 == 0:
+            words.insert(int(rng.integers(0, k)), "needle%d" % (r % 7))
+        contents.append(" ".join(words))
+    c = {"emb": [None] * n, "created": (NOW - rng.integers(0, 100 * DAY, n)).astype(np.int64), "contents": contents, "dim": 0}
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    many = " ".join("t%03d" % i for i in range(150)) + " needle3 lorem"
+    for text in ("needle3", "needle1 needle2 zzz", "m", "or", "sit amet", "consectetur adipiscing", many,
+                 "lorem ipsum dolor sit amet consectetur adipiscing elit needle0 needle6"):
+        assert_same_ranking(idx, corpus, c, None, text, 15, n)
+    idx.close()
+
+
+def test_batched_queries_equal_single_queries():
+    P = pkg()
+    rng = np.random.default_rng(21)
+    c = random_corpus(rng, 3000, 128, sorted_created=True)
+    idx = build_index(c)
+    B = 11
+    qs = rng.standard_normal((B, 128)).astype(np.float32)
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=3000)
+    corpus = oracle_corpus(c)
+    for b in range(B):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=3000)
+        assert list(rows[b]) == list(orow) and np.array_equal(scores[b], osc)
+    idx.close()
+
+
+def test_config_c1_1k_by_768_limit_300_and_1000():
+    """BASELINE.json configs[0]: 1k chunks x 768-d, single query, candidate_limit 300 (reference) and 1000."""
+    P = pkg()
+    syn = importlib.import_module("omni_recall_rag_amd.synthetic")
+    n, dim = 1000, 768
+    emb = syn.embeddings(0, n, dim).numpy()
+    created = syn.created_ticks(0, n, n).numpy()
+    pool, off = syn.contents(0, n)
+    idx = P.RecallIndex(dim=dim)
+    idx.append(emb, created, pool.numpy(), off.numpy())
+    idx.seal()
+    corpus = orc.OracleCorpus(emb, created, (pool.numpy(), off.numpy()))
+    for b in range(4):
+        q = syn.query_vectors(b, 1, dim, n).numpy()[0]
+        text = syn.query_texts(b, 1, n)[0]
+        for limit in (300, 1000):
+            rows, scores, counts = idx.search(q[None, :], [P.text.query_terms(text)], syn.NOW_TICKS, 10, candidate_limit=limit)
+            orow, osc, _ = corpus.search(q, text, syn.NOW_TICKS, 10, candidate_limit=limit)
+            assert list(rows[0]) == list(orow) and np.array_equal(scores[0], osc)
+        assert rows[0, 0] == syn.planted_rows(b, 1, n)[0]
+    idx.close()
+
+
+def test_two_shards_on_one_gpu_equal_one_shard():
+    """Row-sharded search + host merge gives the same ranking as the single index."""
+    P = pkg()
+    rng = np.random.default_rng(33)
+    n, dim, B, k = 6000, 128, 5, 10
+    c = random_corpus(rng, n, dim, sorted_created=True)
+    whole = build_index(c)
+    cut = 2500
+    parts = []
+    for lo, hi in ((0, cut), (cut, n)):
+        sub = {"emb": c["emb"][lo:hi], "created": c["created"][lo:hi], "contents": c["contents"][lo:hi], "dim": dim}
+        parts.append(build_index(sub, row_base=lo))
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    texts = [QUERY_TEXTS[b] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    for limit in (n, 300, 3000):
+        rows, scores, counts = whole.search(qs, terms, NOW, k, candidate_limit=limit)
+        recs = np.stack([p.search_shard(qs, terms, NOW, 32, limit) for p in parts])
+        mrows, mscores, mcounts, unc = P.merge_candidates(recs, dim, qs, terms, NOW, k)
+        assert unc == 0
+        assert np.array_equal(rows, mrows) and np.array_equal(scores, mscores) and np.array_equal(counts, mcounts)
+    whole.close()
+    for p in parts:
+        p.close()

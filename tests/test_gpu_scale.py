@@ -1,0 +1,72 @@
+"""Parity at BASELINE.json's bench size (1M x 3072) through size-independent
+properties, plus an oracle check on a sub-range the CPU finishes in seconds."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import orc, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    P = pkg()
+    syn = importlib.import_module("omni_recall_rag_amd.synthetic")
+    n, dim = 1_000_000, 3072
+    idx = P.RecallIndex(dim=dim, capacity_rows=n)
+    step = 32768
+    for r0 in range(0, n, step):
+        m = min(step, n - r0)
+        pool, off = syn.contents(r0, m, "cuda:0")
+        idx.append(syn.embeddings(r0, m, dim, "cuda:0"), syn.created_ticks(r0, m, n, "cuda:0"), pool, off)
+    torch.cuda.synchronize()
+    idx.seal()
+    yield P, syn, idx, n, dim
+    idx.close()
+
+
+def test_planted_rows_win_and_batches_agree_at_1m(big):
+    P, syn, idx, n, dim = big
+    B = 4
+    q = syn.query_vectors(0, B, dim, n, "cuda:0")
+    texts = syn.query_texts(0, B, n)
+    terms = [P.text.query_terms(t) for t in texts]
+    rows, scores, counts = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n)
+    planted = syn.planted_rows(0, B, n)
+    assert list(rows[:, 0]) == planted                      # the planted row is rank 1
+    assert (counts == 10).all()
+    assert (np.diff(scores, axis=1) <= 0).all()             # sorted by score
+    for b in range(B):                                      # one by one == batched (idempotence)
+        r1, s1, _ = idx.search(q[b:b + 1], terms[b:b + 1], syn.NOW_TICKS, 10, candidate_limit=n)
+        assert np.array_equal(r1[0], rows[b]) and np.array_equal(s1[0], scores[b])
+    # the winner's score, recomputed by the oracle from regenerated inputs
+    for b in range(B):
+        r = planted[b]
+        e = syn.embeddings(r, 1, dim).numpy()[0]
+        pool, off = syn.contents(r, 1)
+        created = int(syn.created_ticks(r, 1, n)[0])
+        cor = orc.OracleCorpus(e[None, :], [created], (pool.numpy(), off.numpy()))
+        _, osc, _ = cor.search(q[b].cpu().numpy(), texts[b], syn.NOW_TICKS, 1, candidate_limit=1)
+        assert scores[b, 0] == osc[0]
+
+
+def test_candidate_limit_prefix_against_oracle_at_1m(big):
+    """candidate_limit = 20000 scores only the newest 20000 rows: small enough for the oracle."""
+    P, syn, idx, n, dim = big
+    m = 20000
+    emb = syn.embeddings(0, m, dim).numpy()
+    created = syn.created_ticks(0, m, n).numpy()
+    pool, off = syn.contents(0, m)
+    cor = orc.OracleCorpus(emb, created, (pool.numpy(), off.numpy()))
+    for b in (0, 1):
+        q = syn.query_vectors(b, 1, dim, n).numpy()
+        text = syn.query_texts(b, 1, n)[0]
+        rows, scores, _ = idx.search(q, [P.text.query_terms(text)], syn.NOW_TICKS, 10, candidate_limit=m)
+        orow, osc, _ = cor.search(q[0], text, syn.NOW_TICKS, 10, candidate_limit=m, threads=8)
+        assert list(rows[0]) == list(orow) and np.array_equal(scores[0], osc)
+        r300, s300, _ = idx.search(q, [P.text.query_terms(text)], syn.NOW_TICKS, 10, candidate_limit=300)
+        o300, os300, _ = cor.search(q[0], text, syn.NOW_TICKS, 10, candidate_limit=300)
+        assert list(r300[0]) == list(o300) and np.array_equal(s300[0], os300)
