@@ -202,7 +202,10 @@ def test_two_shards_on_one_gpu_equal_one_shard():
     P = pkg()
     rng = np.random.default_rng(33)
     n, dim, B, k = 6000, 128, 5, 10
-    c = random_corpus(rng, n, dim, sorted_created=True)
+    c = random_corpus(rng, n, dim)
+    order = np.argsort(-c["created"], kind="stable")          # shards are contiguous ranges of the candidate order
+    c = {"emb": [c["emb"][i] for i in order], "created": c["created"][order],
+         "contents": [c["contents"][i] for i in order], "dim": dim}
     whole = build_index(c)
     cut = 2500
     parts = []
