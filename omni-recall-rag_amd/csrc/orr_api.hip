@@ -95,7 +95,9 @@ struct orr_index {
     int device = 0;
     int32_t dim = 0;
     int64_t row_base = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: dots, fused score, selection
+    hipStream_t stream_kw = nullptr;   // keyword scan runs beside the HBM-bound dot kernel
+    hipEvent_t ev_inputs = nullptr, ev_kw_done = nullptr;
     std::mutex mu;
 
     // corpus, in append order until seal, in candidate order afterwards
@@ -103,17 +105,21 @@ struct orr_index {
     float *d_emb = nullptr;
     int64_t *d_created = nullptr;
     int64_t *d_row_ids = nullptr;
-    uint64_t *d_off = nullptr;         // [cap_rows+1]
+    // lowercased content: row r = d_pool[d_cstart[r] .. +d_clen[r]), starts 16-byte aligned,
+    // each row followed by 1..16 spaces (see keyword_scan_kernel)
+    uint64_t *d_cstart = nullptr;      // [cap_rows]
+    uint32_t *d_clen = nullptr;        // [cap_rows]
     uint8_t *d_pool = nullptr;
     uint64_t pool_len = 0, pool_cap = 0;
     double *d_norm_b = nullptr;
-    std::vector<int64_t> h_created;    // host mirror (seal-time ordering, merge)
-    std::vector<uint64_t> h_off;       // host mirror of content offsets
+    std::vector<int64_t> h_created;    // host mirror (seal-time ordering)
+    std::vector<uint32_t> h_clen;      // host mirror of content lengths
+    std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     bool sealed = false;
 
     // search workspace
     DevBuf ws_q, ws_dot, ws_matches, ws_sel, ws_cand, ws_qc, ws_terms, ws_term_pool, ws_qoff;
-    DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp;
+    DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
 
     // profiling
     bool profiling = false;
@@ -151,19 +157,21 @@ struct Timed {
     orr_index *idx;
     PendingEvent pe;
     bool on;
-    Timed(orr_index *i, const char *name, double algo_bytes) : idx(i), on(i->profiling)
+    hipStream_t st;
+    Timed(orr_index *i, const char *name, double algo_bytes, hipStream_t stream = nullptr)
+        : idx(i), on(i->profiling), st(stream ? stream : i->stream)
     {
         if (!on) return;
         pe.stat = stat_slot(idx, name);
         idx->stats[pe.stat].algo_bytes += algo_bytes;
         pe.start = take_event(idx);
         pe.stop = take_event(idx);
-        (void)hipEventRecord(pe.start, idx->stream);
+        (void)hipEventRecord(pe.start, st);
     }
     ~Timed()
     {
         if (!on) return;
-        (void)hipEventRecord(pe.stop, idx->stream);
+        (void)hipEventRecord(pe.stop, st);
         idx->pending.push_back(pe);
     }
 };
@@ -227,7 +235,8 @@ int ensure_row_capacity(orr_index *idx, int64_t rows)
     if (idx->dim > 0) ORR_TRY(dev_grow(&idx->d_emb, (size_t)idx->n_rows * idx->dim, (size_t)nc * idx->dim, idx->stream));
     ORR_TRY(dev_grow(&idx->d_created, (size_t)idx->n_rows, (size_t)nc, idx->stream));
     ORR_TRY(dev_grow(&idx->d_row_ids, (size_t)idx->n_rows, (size_t)nc, idx->stream));
-    ORR_TRY(dev_grow(&idx->d_off, (size_t)idx->n_rows + 1, (size_t)nc + 1, idx->stream));
+    ORR_TRY(dev_grow(&idx->d_cstart, (size_t)idx->n_rows, (size_t)nc, idx->stream));
+    ORR_TRY(dev_grow(&idx->d_clen, (size_t)idx->n_rows, (size_t)nc, idx->stream));
     idx->cap_rows = nc;
     return ORR_OK;
 }
@@ -332,9 +341,12 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
     idx->device = cfg->device;
     idx->dim = cfg->dim;
     idx->row_base = cfg->row_base;
-    if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete idx;
-        return fail(ORR_EDEVICE, "cannot create a stream on device %d", cfg->device);
+    if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&idx->stream_kw, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_inputs, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_kw_done, hipEventDisableTiming) != hipSuccess) {
+        orr_index_destroy(idx);
+        return fail(ORR_EDEVICE, "cannot create streams on device %d", cfg->device);
     }
     if (cfg->capacity_rows > 0) {
         int r = ensure_row_capacity(idx, cfg->capacity_rows);
@@ -349,17 +361,22 @@ void orr_index_destroy(orr_index *idx)
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
+    if (idx->stream_kw) (void)hipStreamSynchronize(idx->stream_kw);
+    if (idx->ev_inputs) (void)hipEventDestroy(idx->ev_inputs);
+    if (idx->ev_kw_done) (void)hipEventDestroy(idx->ev_kw_done);
+    if (idx->stream_kw) (void)hipStreamDestroy(idx->stream_kw);
     for (auto &pe : idx->pending) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
     for (auto e : idx->event_pool) (void)hipEventDestroy(e);
     if (idx->d_emb) (void)hipFree(idx->d_emb);
     if (idx->d_created) (void)hipFree(idx->d_created);
     if (idx->d_row_ids) (void)hipFree(idx->d_row_ids);
-    if (idx->d_off) (void)hipFree(idx->d_off);
+    if (idx->d_cstart) (void)hipFree(idx->d_cstart);
+    if (idx->d_clen) (void)hipFree(idx->d_clen);
     if (idx->d_pool) (void)hipFree(idx->d_pool);
     if (idx->d_norm_b) (void)hipFree(idx->d_norm_b);
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_matches, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc,
                       &idx->ws_terms, &idx->ws_term_pool, &idx->ws_qoff, &idx->ws_keys_a, &idx->ws_keys_b,
-                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp};
+                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start};
     for (auto b : bufs) b->release();
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
@@ -391,14 +408,31 @@ int orr_index_append(orr_index *idx, int64_t n, int32_t dim, const float *emb, c
         if (off[i + 1] < off[i]) return fail(ORR_EINVAL, "orr_index_append: content_off is not monotone at row %lld", (long long)i);
     const uint64_t bytes = off[n] - off[0];
     if (bytes > 0 && !content_lower) return fail(ORR_EINVAL, "orr_index_append: content_lower is NULL");
-    ORR_TRY(ensure_pool_capacity(idx, idx->pool_len + bytes));
-    if (bytes > 0)
-        HIP_TRY(hipMemcpyAsync(idx->d_pool + idx->pool_len, content_lower + off[0], bytes, hipMemcpyDefault, idx->stream));
-    if (idx->h_off.empty()) idx->h_off.push_back(0);
-    for (int64_t i = 0; i < n; ++i) idx->h_off.push_back(idx->pool_len + (off[i + 1] - off[0]));
-    HIP_TRY(hipMemcpyAsync(idx->d_off + idx->n_rows, idx->h_off.data() + idx->n_rows, sizeof(uint64_t) * ((size_t)n + 1),
-                           hipMemcpyHostToDevice, idx->stream));
-    idx->pool_len += bytes;
+    // re-lay the rows out for the scan kernel: 16-byte aligned starts, space padding behind each row
+    std::vector<uint64_t> src_start((size_t)n), dst_start((size_t)n);
+    std::vector<uint32_t> lens((size_t)n);
+    uint64_t cursor = idx->pool_len;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t len = off[i + 1] - off[i];
+        if (len >= (1ull << 31)) return fail(ORR_EINVAL, "orr_index_append: content of row %lld exceeds 2 GiB", (long long)i);
+        src_start[i] = off[i] - off[0];
+        dst_start[i] = cursor;
+        lens[i] = (uint32_t)len;
+        cursor += orr::padded_row_bytes(len);
+    }
+    ORR_TRY(ensure_pool_capacity(idx, cursor));
+    HIP_TRY(hipMemsetAsync(idx->d_pool + idx->pool_len, 0x20, cursor - idx->pool_len, idx->stream));
+    HIP_TRY(hipMemcpyAsync(idx->d_cstart + idx->n_rows, dst_start.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, idx->stream));
+    HIP_TRY(hipMemcpyAsync(idx->d_clen + idx->n_rows, lens.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, idx->stream));
+    if (bytes > 0) {
+        ORR_TRY(idx->ws_raw.reserve(bytes));
+        ORR_TRY(idx->ws_src_start.reserve(sizeof(uint64_t) * (size_t)n));
+        HIP_TRY(hipMemcpyAsync(idx->ws_raw.p, content_lower + off[0], bytes, hipMemcpyDefault, idx->stream));
+        HIP_TRY(hipMemcpyAsync(idx->ws_src_start.p, src_start.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, idx->stream));
+        HIP_TRY(orr::launch_gather_content(idx->ws_raw.as<uint8_t>(), idx->ws_src_start.as<uint64_t>(), idx->d_clen + idx->n_rows,
+                                           idx->d_pool, idx->d_cstart + idx->n_rows, nullptr, n, idx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(idx->stream));
 
     // timestamps (host mirror + device)
     const size_t old = idx->h_created.size();
@@ -422,6 +456,8 @@ int orr_index_append(orr_index *idx, int64_t n, int32_t dim, const float *emb, c
     else
         HIP_TRY(orr::launch_iota_i64(idx->d_row_ids + idx->n_rows, n, idx->row_base + idx->n_rows, idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->h_clen.insert(idx->h_clen.end(), lens.begin(), lens.end());
+    idx->pool_len = cursor;
     idx->n_rows += n;
     return ORR_OK;
 }
@@ -458,26 +494,39 @@ int orr_index_seal(orr_index *idx)
         ORR_TRY(dev_alloc(&nr, (size_t)idx->cap_rows));
         HIP_TRY(orr::launch_gather_i64(idx->d_created, nc, d_perm, n, idx->stream));
         HIP_TRY(orr::launch_gather_i64(idx->d_row_ids, nr, d_perm, n, idx->stream));
-        std::vector<uint64_t> noff((size_t)n + 1);
-        noff[0] = 0;
-        for (int64_t p = 0; p < n; ++p) noff[p + 1] = noff[p] + (idx->h_off[perm[p] + 1] - idx->h_off[perm[p]]);
-        uint64_t *d_noff = nullptr;
+        std::vector<uint64_t> nstart((size_t)n);
+        std::vector<uint32_t> nlen((size_t)n);
+        uint64_t cursor = 0;
+        for (int64_t p = 0; p < n; ++p) {
+            nlen[p] = idx->h_clen[perm[p]];
+            nstart[p] = cursor;
+            cursor += orr::padded_row_bytes(nlen[p]);
+        }
+        uint64_t *d_nstart = nullptr;
+        uint32_t *d_nlen = nullptr;
         uint8_t *npool = nullptr;
-        ORR_TRY(dev_alloc(&d_noff, (size_t)idx->cap_rows + 1));
+        ORR_TRY(dev_alloc(&d_nstart, (size_t)idx->cap_rows));
+        ORR_TRY(dev_alloc(&d_nlen, (size_t)idx->cap_rows));
         ORR_TRY(dev_alloc(&npool, (size_t)idx->pool_cap));
-        HIP_TRY(hipMemcpyAsync(d_noff, noff.data(), sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, idx->stream));
-        HIP_TRY(orr::launch_gather_content(idx->d_pool, idx->d_off, npool, d_noff, d_perm, n, idx->stream));
+        HIP_TRY(hipMemsetAsync(npool, 0x20, cursor, idx->stream));
+        HIP_TRY(hipMemcpyAsync(d_nstart, nstart.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, idx->stream));
+        HIP_TRY(orr::launch_gather_content(idx->d_pool, idx->d_cstart, idx->d_clen, npool, d_nstart, d_perm, n, idx->stream));
+        HIP_TRY(orr::launch_gather_u32(idx->d_clen, d_nlen, d_perm, n, idx->stream));
         HIP_TRY(hipStreamSynchronize(idx->stream));
         (void)hipFree(idx->d_created); idx->d_created = nc;
         (void)hipFree(idx->d_row_ids); idx->d_row_ids = nr;
-        (void)hipFree(idx->d_off); idx->d_off = d_noff;
+        (void)hipFree(idx->d_cstart); idx->d_cstart = d_nstart;
+        (void)hipFree(idx->d_clen); idx->d_clen = d_nlen;
         (void)hipFree(idx->d_pool); idx->d_pool = npool;
+        idx->pool_len = cursor;
         (void)hipFree(d_perm);
         std::vector<int64_t> sorted_created((size_t)n);
         for (int64_t p = 0; p < n; ++p) sorted_created[p] = cr[perm[p]];
         idx->h_created.swap(sorted_created);
-        idx->h_off.swap(noff);
+        idx->h_clen.swap(nlen);
     }
+    idx->h_cprefix.assign((size_t)n + 1, 0);
+    for (int64_t p = 0; p < n; ++p) idx->h_cprefix[p + 1] = idx->h_cprefix[p] + idx->h_clen[p];
 
     // K0: exact row norms, sum_i (double)fl32(e_i*e_i) (RecallSearchService.cs:81)
     ORR_TRY(dev_alloc(&idx->d_norm_b, (size_t)std::max<int64_t>(n, 1)));
@@ -601,21 +650,6 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, std::vector<fl
         return ORR_OK;
     }
 
-    // K1e exact dots, kMaxExactQ queries per launch
-    double *d_dot = nullptr;
-    if (use_cos) {
-        ORR_TRY(idx->ws_q.reserve(sizeof(float) * (size_t)B * a.dim));
-        ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
-        HIP_TRY(hipMemcpyAsync(idx->ws_q.p, q_host.data(), sizeof(float) * q_host.size(), hipMemcpyHostToDevice, s));
-        d_dot = idx->ws_dot.as<double>();
-        for (int32_t b0 = 0; b0 < B; b0 += orr::kMaxExactQ) {
-            const int32_t nq = std::min<int32_t>(orr::kMaxExactQ, B - b0);
-            Timed t(idx, "dot_exact", 4.0 * (double)n * idx->dim + 4.0 * nq * idx->dim + 8.0 * nq * (double)n);
-            HIP_TRY(orr::launch_dot_exact(idx->d_emb, n, idx->dim, idx->ws_q.as<float>() + (size_t)b0 * a.dim, nq, false,
-                                          d_dot + (size_t)b0 * n, n, s));
-        }
-    }
-
     // K3 keyword scan
     uint16_t *d_matches = nullptr;
     if (n_terms_total > 0) {
@@ -675,15 +709,36 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, std::vector<fl
         }
         ORR_TRY(idx->ws_qoff.reserve(sizeof(uint32_t) * rel.size()));
         HIP_TRY(hipMemcpyAsync(idx->ws_qoff.p, rel.data(), sizeof(uint32_t) * rel.size(), hipMemcpyHostToDevice, s));
-        const double content_bytes = (double)(idx->h_off[n] - idx->h_off[0]);
+        const double content_bytes = (double)idx->h_cprefix[n];
+        // the scan runs on its own stream beside the HBM-bound dot kernel
+        HIP_TRY(hipEventRecord(idx->ev_inputs, s));
+        HIP_TRY(hipStreamWaitEvent(idx->stream_kw, idx->ev_inputs, 0));
         for (const auto &L : launches) {
-            Timed t(idx, "keyword_scan", content_bytes + 8.0 * (double)(n + 1) + 2.0 * L.nb * (double)n);
-            HIP_TRY(orr::launch_keyword_scan(idx->d_pool, idx->d_off, n, idx->ws_term_pool.as<uint8_t>(),
+            Timed t(idx, "keyword_scan", content_bytes + 12.0 * (double)n + 2.0 * L.nb * (double)n, idx->stream_kw);
+            HIP_TRY(orr::launch_keyword_scan(idx->d_pool, idx->d_cstart, idx->d_clen, n, idx->ws_term_pool.as<uint8_t>(),
                                              idx->ws_terms.as<orr::ScanTerm>() + L.t0, (int32_t)L.nt,
                                              idx->ws_qoff.as<uint32_t>() + L.rel_at, L.nb,
-                                             d_matches + (size_t)L.b0 * n, n, L.acc, s));
+                                             d_matches + (size_t)L.b0 * n, n, L.acc, idx->stream_kw));
+        }
+        HIP_TRY(hipEventRecord(idx->ev_kw_done, idx->stream_kw));
+    }
+
+    // K1e exact dots, kMaxExactQ queries per launch
+    double *d_dot = nullptr;
+    if (use_cos) {
+        ORR_TRY(idx->ws_q.reserve(sizeof(float) * (size_t)B * a.dim));
+        ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
+        HIP_TRY(hipMemcpyAsync(idx->ws_q.p, q_host.data(), sizeof(float) * q_host.size(), hipMemcpyHostToDevice, s));
+        d_dot = idx->ws_dot.as<double>();
+        for (int32_t b0 = 0; b0 < B; b0 += orr::kMaxExactQ) {
+            const int32_t nq = std::min<int32_t>(orr::kMaxExactQ, B - b0);
+            Timed t(idx, "dot_exact", 4.0 * (double)n * idx->dim + 4.0 * nq * idx->dim + 8.0 * nq * (double)n);
+            HIP_TRY(orr::launch_dot_exact(idx->d_emb, n, idx->dim, idx->ws_q.as<float>() + (size_t)b0 * a.dim, nq, false,
+                                          d_dot + (size_t)b0 * n, n, s));
         }
     }
+
+    if (n_terms_total > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_kw_done, 0));
 
     // K4/K5 fused score + selection
     if (kprime <= orr::kSelWidth) {

@@ -39,10 +39,14 @@ hipError_t launch_dot_exact(const float *E, int64_t n_rows, int32_t D, const flo
 // K3: matches[b][r] = number of terms of query b that occur in row r's content
 // (RecallSearchService.cs:111).  n_terms <= kMaxScanTerms; q_term_off[B+1] indexes
 // into terms[0..n_terms).  accumulate != 0 adds to matches instead of overwriting (a
-// query with more than kMaxScanTerms terms is scanned in several launches).  The pool
-// must be over-allocated by kScanPoolSlack bytes.
+// query with more than kMaxScanTerms terms is scanned in several launches).
+// Pool layout: row r occupies [cstart[r], cstart[r]+clen[r]), cstart 16-byte aligned,
+// followed by 1..16 space bytes; the pool is over-allocated by kScanPoolSlack bytes.
+// Terms must not contain whitespace bytes.
 constexpr size_t kScanPoolSlack = 2048;
-hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *off, int64_t n_rows,
+constexpr uint64_t kRowAlign = 16;
+inline uint64_t padded_row_bytes(uint64_t len) { return (len / kRowAlign + 1) * kRowAlign; }
+hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *cstart, const uint32_t *clen, int64_t n_rows,
                                const uint8_t *term_pool, const ScanTerm *terms, int32_t n_terms,
                                const uint32_t *q_term_off, int32_t B, uint16_t *matches,
                                int64_t matches_stride, int32_t accumulate, hipStream_t s);
@@ -89,8 +93,11 @@ hipError_t launch_records_from_sorted(const unsigned long long *keys, const uint
 hipError_t launch_gather_rows_f32(const float *src, float *dst, const int64_t *perm, int64_t n, int32_t D,
                                   hipStream_t s);
 hipError_t launch_gather_i64(const int64_t *src, int64_t *dst, const int64_t *perm, int64_t n, hipStream_t s);
-hipError_t launch_gather_content(const uint8_t *src_pool, const uint64_t *src_off, uint8_t *dst_pool,
-                                 const uint64_t *dst_off, const int64_t *perm, int64_t n, hipStream_t s);
+// Content rows: dst row r <- src row perm[r] (perm == nullptr: identity).
+hipError_t launch_gather_content(const uint8_t *src_pool, const uint64_t *src_start, const uint32_t *src_len,
+                                 uint8_t *dst_pool, const uint64_t *dst_start, const int64_t *perm, int64_t n,
+                                 hipStream_t s);
+hipError_t launch_gather_u32(const uint32_t *src, uint32_t *dst, const int64_t *perm, int64_t n, hipStream_t s);
 hipError_t launch_iota_i64(int64_t *dst, int64_t n, int64_t base, hipStream_t s);
 
 }  // namespace orr

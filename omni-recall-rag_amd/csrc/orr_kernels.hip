@@ -15,6 +15,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 namespace orr {
 
 // ---------------------------------------------------------------------------
@@ -62,7 +64,7 @@ __device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t
 // Tile: [64 rows][64 floats] = 16 KiB per wave, 16-byte chunks XOR-swizzled by
 // (row & 15) so that the 16-lane groups of ds_read_b128 hit 16 distinct slots.
 // ---------------------------------------------------------------------------
-template <int NQ, bool SELF>
+template <int NQ, bool SELF, bool PREFETCH>
 __global__ __launch_bounds__(256) void dot_exact_tiled(const float *__restrict__ E, int64_t n_rows, int32_t D,
                                                        const float *__restrict__ Q, double *__restrict__ out,
                                                        int64_t out_stride)
@@ -81,21 +83,29 @@ __global__ __launch_bounds__(256) void dot_exact_tiled(const float *__restrict__
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
 
-        for (int c0 = 0; c0 < D; c0 += 64) {
-            float4 stage[16];
+        // global -> registers: 16 wave instructions of 4 rows x 256 B each
+        auto load_stage = [&](float4 (&st)[16], int c0) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 4 + ld_row;
                 const int64_t row = row0 + r;
-                stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < n_rows)
-                    stage[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
+                    st[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
             }
+        };
+        float4 stage[16];
+        if (PREFETCH) load_stage(stage, 0);
+
+        for (int c0 = 0; c0 < D; c0 += 64) {
+            if (!PREFETCH) load_stage(stage, c0);
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 4 + ld_row;
                 *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
             }
+            // next piece of the rows goes in flight while this one is consumed from LDS
+            if (PREFETCH && c0 + 64 < D) load_stage(stage, c0 + 64);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -170,30 +180,68 @@ hipError_t launch_dot_exact(const float *E, int64_t n_rows, int32_t D, const flo
     }
     const int64_t n_groups = (n_rows + 63) / 64;
     int64_t blocks = (n_groups + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;       // grid-stride beyond 8 workgroups per CU
+    static const int variant = [] { const char *e = getenv("ORR_DOT_VARIANT"); return e ? atoi(e) : 1; }();
+    static const int wg_per_cu = [] { const char *e = getenv("ORR_DOT_WG_PER_CU"); return e ? atoi(e) : 8; }();
+    if (blocks > 256 * (int64_t)wg_per_cu) blocks = 256 * (int64_t)wg_per_cu;   // grid-stride beyond that
     dim3 grid((unsigned)blocks), block(256);
+#define ORR_LAUNCH_DOT(NQ_, SELF_)                                                                                    \
+    do {                                                                                                              \
+        if (variant == 0)                                                                                             \
+            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);  \
+    } while (0)
     if (self_norm) {
-        hipLaunchKernelGGL((dot_exact_tiled<1, true>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);
+        ORR_LAUNCH_DOT(1, true);
     } else {
         switch (nq) {
-        case 1: hipLaunchKernelGGL((dot_exact_tiled<1, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); break;
-        case 2: hipLaunchKernelGGL((dot_exact_tiled<2, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); break;
-        case 3: hipLaunchKernelGGL((dot_exact_tiled<3, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); break;
-        default: hipLaunchKernelGGL((dot_exact_tiled<4, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); break;
+        case 1: ORR_LAUNCH_DOT(1, false); break;
+        case 2: ORR_LAUNCH_DOT(2, false); break;
+        case 3: ORR_LAUNCH_DOT(3, false); break;
+        default: ORR_LAUNCH_DOT(4, false); break;
         }
     }
+#undef ORR_LAUNCH_DOT
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// K3  keyword scan: one wave per row; each lane owns 16 consecutive content
-// bytes per step and tests the 16 start positions in registers against the
-// 4-byte prefix of every term (v_alignbyte windows); longer terms are verified
-// byte-wise only on a prefix hit.  The content pool is over-allocated by 64
-// bytes so the 20-byte reads never leave the allocation.
+// K3  keyword scan.  Device content pool layout (built at append): every row
+// starts on a 16-byte boundary and is followed by 1..16 space bytes up to the next
+// boundary.  Query terms never contain whitespace (they come out of a whitespace
+// split, RecallSearchService.cs:95), so no term can match across a row boundary
+// and only whole lanes past the row end have to be masked.
+//
+// One wave per row; per step each lane owns 16 consecutive content bytes and the
+// 16 four-byte windows starting in them (v_alignbyte), computed once and reused
+// for every term.  A term costs one v_cmp per start position (its lane mask is
+// OR-ed in scalar registers); terms longer than 4 bytes are verified byte-wise
+// only where their 4-byte prefix hit.
 // ---------------------------------------------------------------------------
+// Tells the compiler a value is the same in every lane (it then lives in SGPRs).
+__device__ __forceinline__ int uniform32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <bool FULL_MASK>
+__device__ __forceinline__ unsigned long long prefix_hits(const uint32_t (&win)[16], uint32_t prefix, uint32_t mask)
+{
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t v = FULL_MASK ? win[i] : (win[i] & mask);
+        any |= __ballot(v == prefix);
+    }
+    return any;
+}
+
 __global__ __launch_bounds__(256) void keyword_scan_kernel(const uint8_t *__restrict__ pool,
-                                                           const uint64_t *__restrict__ off, int64_t n_rows,
+                                                           const uint64_t *__restrict__ cstart,
+                                                           const uint32_t *__restrict__ clen, int64_t n_rows,
                                                            const uint8_t *__restrict__ term_pool,
                                                            const ScanTerm *__restrict__ terms, int32_t n_terms,
                                                            const uint32_t *__restrict__ q_term_off, int32_t B,
@@ -201,40 +249,50 @@ __global__ __launch_bounds__(256) void keyword_scan_kernel(const uint8_t *__rest
                                                            int32_t accumulate)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + uniform32((int)(threadIdx.x >> 6));
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
 
     for (int64_t row = wave_id; row < n_rows; row += n_waves) {
-        const uint64_t start = off[row];
-        const int64_t len = (int64_t)(off[row + 1] - start);
-        const uint64_t abase = start & ~(uint64_t)15;
-        const int64_t lead = (int64_t)(start - abase);        // bytes in front of the row in the first chunk
+        const uint64_t start = (uint64_t)uniform64((int64_t)cstart[row]);    // 16-byte aligned
+        const int len = uniform32((int)clen[row]);
         unsigned long long found = 0ull;                      // wave-uniform bit per term
 
-        for (int64_t cb = 0; cb < lead + len; cb += 1024) {
-            const uint8_t *p = pool + abase + cb + lane * 16;
+        for (int cb = 0; cb < len; cb += 1024) {
+            const uint8_t *p = pool + start + cb + lane * 16;
             const uint4 w = *reinterpret_cast<const uint4 *>(p);
             const uint32_t w4 = *reinterpret_cast<const uint32_t *>(p + 16);
-            const uint32_t d[5] = {w.x, w.y, w.z, w.w, w4};
-            const int64_t pos0 = cb + lane * 16 - lead;       // row-relative position of this lane's byte 0
+            uint32_t win[16];
+            win[0] = w.x;  win[1] = __builtin_amdgcn_alignbyte(w.y, w.x, 1);
+            win[2] = __builtin_amdgcn_alignbyte(w.y, w.x, 2);  win[3] = __builtin_amdgcn_alignbyte(w.y, w.x, 3);
+            win[4] = w.y;  win[5] = __builtin_amdgcn_alignbyte(w.z, w.y, 1);
+            win[6] = __builtin_amdgcn_alignbyte(w.z, w.y, 2);  win[7] = __builtin_amdgcn_alignbyte(w.z, w.y, 3);
+            win[8] = w.z;  win[9] = __builtin_amdgcn_alignbyte(w.w, w.z, 1);
+            win[10] = __builtin_amdgcn_alignbyte(w.w, w.z, 2); win[11] = __builtin_amdgcn_alignbyte(w.w, w.z, 3);
+            win[12] = w.w; win[13] = __builtin_amdgcn_alignbyte(w4, w.w, 1);
+            win[14] = __builtin_amdgcn_alignbyte(w4, w.w, 2);  win[15] = __builtin_amdgcn_alignbyte(w4, w.w, 3);
+            // lanes whose 16 bytes begin inside the row (later lanes hold padding or the next row)
+            const int live = (len - cb + 15) >> 4;
+            const unsigned long long live_mask = live >= 64 ? ~0ull : ((1ull << live) - 1ull);
 
             for (int t = 0; t < n_terms; ++t) {
                 if ((found >> t) & 1ull) continue;
                 const ScanTerm tm = terms[t];
-                const int64_t last = len - (int64_t)tm.len;   // last valid start position
+                if (tm.len == 0 || (int)tm.len > len) continue;
+                unsigned long long any = (tm.mask == 0xFFFFFFFFu) ? prefix_hits<true>(win, tm.prefix, tm.mask)
+                                                                  : prefix_hits<false>(win, tm.prefix, tm.mask);
+                any &= live_mask;
+                if (any == 0ull) continue;
+                if (tm.len <= 4) { found |= (1ull << t); continue; }
+                // rare: the 4-byte prefix hit somewhere in this step; verify the tail where it hit
                 bool hit = false;
-                if (tm.len > 0 && last >= 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const uint32_t win = (i & 3) ? __builtin_amdgcn_alignbyte(d[(i >> 2) + 1], d[i >> 2], i & 3)
-                                                     : d[i >> 2];
-                        const int64_t pos = pos0 + i;
-                        if (((win & tm.mask) == tm.prefix) && pos >= 0 && pos <= last) {
-                            bool ok = true;
-                            for (uint32_t k = 4; k < tm.len; ++k)
-                                ok = ok && (pool[start + pos + k] == term_pool[tm.off + k]);
-                            hit = hit || ok;
-                        }
+                const int pos0 = cb + lane * 16;
+                for (int i = 0; i < 16; ++i) {
+                    const int pos = pos0 + i;
+                    if (win[i] == tm.prefix && pos + (int)tm.len <= len) {
+                        bool ok = true;
+                        for (uint32_t k = 4; k < tm.len; ++k)
+                            ok = ok && (pool[start + pos + k] == term_pool[tm.off + k]);
+                        hit = hit || ok;
                     }
                 }
                 if (__any(hit)) found |= (1ull << t);
@@ -251,7 +309,7 @@ __global__ __launch_bounds__(256) void keyword_scan_kernel(const uint8_t *__rest
     }
 }
 
-hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *off, int64_t n_rows,
+hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *cstart, const uint32_t *clen, int64_t n_rows,
                                const uint8_t *term_pool, const ScanTerm *terms, int32_t n_terms,
                                const uint32_t *q_term_off, int32_t B, uint16_t *matches,
                                int64_t matches_stride, int32_t accumulate, hipStream_t s)
@@ -260,7 +318,7 @@ hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *off, int64_t
     if (n_terms > kMaxScanTerms || B > 64) return hipErrorInvalidValue;
     int64_t blocks = (n_rows + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(keyword_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pool, off, n_rows, term_pool,
+    hipLaunchKernelGGL(keyword_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pool, cstart, clen, n_rows, term_pool,
                        terms, n_terms, q_term_off, B, matches, matches_stride, accumulate);
     return hipGetLastError();
 }
@@ -337,21 +395,31 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const double *__restri
 
     unsigned long long k = 0ull;
     uint32_t p = 0xFFFFFFFFu;
-    for (int64_t base = seg0 + wave * 64; base < seg1; base += 256) {
-        const int64_t r = base + lane;
-        unsigned long long nk = 0ull;
-        uint32_t np = 0xFFFFFFFFu;
-        if (r < seg1) {
-            const double d = qc.use_cos ? dot[(int64_t)b * dot_stride + r] : 0.0;
-            const uint32_t m = qc.n_terms > 0 ? matches[(int64_t)b * matches_stride + r] : 0u;
-            nk = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
-            np = (uint32_t)r;
+    constexpr int U = 4;     // batches scored together so that their loads are in flight at once
+    for (int64_t base = seg0 + wave * 64; base < seg1; base += 256 * U) {
+        unsigned long long nk[U];
+        uint32_t np[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = base + 256 * u + lane;
+            nk[u] = 0ull;
+            np[u] = 0xFFFFFFFFu;
+            if (r < seg1) {
+                const double d = qc.use_cos ? dot[(int64_t)b * dot_stride + r] : 0.0;
+                const uint32_t m = qc.n_terms > 0 ? matches[(int64_t)b * matches_stride + r] : 0u;
+                nk[u] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
+                np[u] = (uint32_t)r;
+            }
         }
-        const unsigned long long tk = __shfl(k, 63, 64);
-        const uint32_t tp = __shfl(p, 63, 64);
-        if (!__any(better(nk, np, tk, tp))) continue;
-        wave_sort(nk, np, lane);
-        wave_merge_sorted(k, p, nk, np, lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + 256 * u >= seg1) break;
+            const unsigned long long tk = __shfl(k, 63, 64);
+            const uint32_t tp = __shfl(p, 63, 64);
+            if (!__any(better(nk[u], np[u], tk, tp))) continue;
+            wave_sort(nk[u], np[u], lane);
+            wave_merge_sorted(k, p, nk[u], np[u], lane);
+        }
     }
     lists[wave][lane].key = k;
     lists[wave][lane].pos = p;
@@ -421,9 +489,20 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
 
     unsigned long long k = 0ull;
     uint32_t p = 0xFFFFFFFFu;
-    for (int sgi = wave; sgi < n_seg; sgi += 16) {
-        const SelEntry e = mine[(int64_t)sgi * kSelWidth + lane];
-        wave_merge_sorted(k, p, e.key, e.pos, lane);
+    constexpr int U = 4;     // lists fetched together
+    for (int sg0 = wave; sg0 < n_seg; sg0 += 16 * U) {
+        SelEntry e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sgi = sg0 + 16 * u;
+            e[u].key = 0ull; e[u].pos = 0xFFFFFFFFu;
+            if (sgi < n_seg) e[u] = mine[(int64_t)sgi * kSelWidth + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (sg0 + 16 * u >= n_seg) break;
+            wave_merge_sorted(k, p, e[u].key, e[u].pos, lane);
+        }
     }
     lists[wave][lane].key = k;
     lists[wave][lane].pos = p;
@@ -567,20 +646,31 @@ __global__ __launch_bounds__(256) void gather_i64_kernel(const int64_t *__restri
         dst[r] = src[perm[r]];
 }
 
+// dst row r <- src row perm[r] (perm == nullptr: identity).  Source rows are
+// (src_start, len) byte ranges; destination rows start at dst_start[r].
 __global__ __launch_bounds__(256) void gather_content_kernel(const uint8_t *__restrict__ src_pool,
-                                                             const uint64_t *__restrict__ src_off,
+                                                             const uint64_t *__restrict__ src_start,
+                                                             const uint32_t *__restrict__ src_len,
                                                              uint8_t *__restrict__ dst_pool,
-                                                             const uint64_t *__restrict__ dst_off,
+                                                             const uint64_t *__restrict__ dst_start,
                                                              const int64_t *__restrict__ perm, int64_t n)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave_id; r < n; r += n_waves) {
-        const int64_t sr = perm[r];
-        const uint64_t s0 = src_off[sr], len = src_off[sr + 1] - s0, d0 = dst_off[r];
-        for (uint64_t i = lane; i < len; i += 64) dst_pool[d0 + i] = src_pool[s0 + i];
+        const int64_t sr = perm ? perm[r] : r;
+        const uint64_t s0 = src_start[sr], d0 = dst_start[r];
+        const uint32_t len = src_len[sr];
+        for (uint32_t i = lane; i < len; i += 64) dst_pool[d0 + i] = src_pool[s0 + i];
     }
+}
+
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                         const int64_t *__restrict__ perm, int64_t n)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+        dst[r] = src[perm[r]];
 }
 
 __global__ __launch_bounds__(256) void iota_i64_kernel(int64_t *__restrict__ dst, int64_t n, int64_t base)
@@ -611,12 +701,20 @@ hipError_t launch_gather_i64(const int64_t *src, int64_t *dst, const int64_t *pe
     return hipGetLastError();
 }
 
-hipError_t launch_gather_content(const uint8_t *src_pool, const uint64_t *src_off, uint8_t *dst_pool,
-                                 const uint64_t *dst_off, const int64_t *perm, int64_t n, hipStream_t s)
+hipError_t launch_gather_content(const uint8_t *src_pool, const uint64_t *src_start, const uint32_t *src_len,
+                                 uint8_t *dst_pool, const uint64_t *dst_start, const int64_t *perm, int64_t n,
+                                 hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_content_kernel, dim3(capped_blocks(n, 4)), dim3(256), 0, s, src_pool, src_off, dst_pool,
-                       dst_off, perm, n);
+    hipLaunchKernelGGL(gather_content_kernel, dim3(capped_blocks(n, 4)), dim3(256), 0, s, src_pool, src_start, src_len,
+                       dst_pool, dst_start, perm, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_u32(const uint32_t *src, uint32_t *dst, const int64_t *perm, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(capped_blocks(n, 256)), dim3(256), 0, s, src, dst, perm, n);
     return hipGetLastError();
 }
 
