@@ -162,12 +162,22 @@ def main():
         queries = args.steps * world * B_local
         dom = stats.get("dot_exact", {"launches": 0, "total_ms": 0.0, "algo_bytes": 0.0})
         roofline = None
+        # HBM bytes per dot_exact launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload shape.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc_path) and (rows, dim, B_local) == (1_000_000, 3072, 1):
+            with open(pmc_path) as f:
+                for kname, kv in json.load(f)["kernels"].items():
+                    if kname.startswith("orr::dot_exact_tiled<1, false") and "hbm_bytes_per_launch_corrected" in kv:
+                        traffic = kv["hbm_bytes_per_launch_corrected"]
         if dom["launches"]:
             avg_ms = dom["total_ms"] / dom["launches"]
             bytes_per_launch = dom["algo_bytes"] / dom["launches"]
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "dot_exact", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                         "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
         out = {
             "metric": "queries/sec at top-k=10 over N x 3072-d chunks",

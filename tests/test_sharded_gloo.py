@@ -1,0 +1,52 @@
+"""N>1 path on CPU: two gloo ranks, each owning half of the candidate order; query
+exchange, one all-gather of per-shard candidate records, host merge with k'
+escalation.  Results must equal the oracle over the whole corpus."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_search_over_gloo(tmp_path, world):
+    port = _free_port()
+    res = str(tmp_path / "res")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world),
+                               str(port), "240", "16", "77", res], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][-3000:]
+        assert open(res + ".%d" % r).read() == "ok", outs[r][-3000:]
+
+
+def test_term_slot_roundtrip():
+    import importlib
+    import __graft_entry__ as graft
+    graft.load_package()
+    sh = importlib.import_module(graft.PKG_NAME + ".sharded")
+    for terms in ([], [b"a"], [b"kubernetes", "naïve".encode(), b"x" * 100]):
+        assert sh._unpack_terms_fixed(sh._pack_terms_fixed(terms)) == terms
+    with pytest.raises(ValueError):
+        sh._pack_terms_fixed([b"y" * 200, b"z" * 100])
