@@ -18,9 +18,13 @@
 #include <new>
 #include <numeric>
 #include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "orr_kernels.h"
+#include "orr_token_index.h"
 
 namespace {
 
@@ -77,6 +81,33 @@ struct DevBuf {
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Grow-only pinned host buffer (device-visible): small uploads, the query copy, and the
+// candidate records the last kernel writes straight into host memory.
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return ORR_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(ORR_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return ORR_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
 struct KernelStat {
     std::string name;
     int64_t launches = 0;
@@ -112,14 +143,25 @@ struct orr_index {
     uint8_t *d_pool = nullptr;
     uint64_t pool_len = 0, pool_cap = 0;
     double *d_norm_b = nullptr;
+    // after seal the raw content is replaced by the token index (orr_token_index.cpp)
+    int64_t n_tokens = 0;
+    uint8_t *d_vpool = nullptr;        // vocabulary in the scan kernel's row layout
+    uint64_t *d_vstart = nullptr;      // [n_tokens]
+    uint32_t *d_vlen = nullptr;        // [n_tokens]
+    uint64_t *d_post_off = nullptr;    // [n_tokens+1]
+    uint32_t *d_post_rows = nullptr;   // ascending candidate positions per token
+    uint64_t n_postings = 0;
     std::vector<int64_t> h_created;    // host mirror (seal-time ordering)
     std::vector<uint32_t> h_clen;      // host mirror of content lengths
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     bool sealed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_matches, ws_sel, ws_cand, ws_qc, ws_terms, ws_term_pool, ws_qoff;
+    DevBuf ws_q, ws_dot, ws_sel, ws_cand, ws_qc;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
+    DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
+    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
+    hipEvent_t ev_q = nullptr;
 
     // profiling
     bool profiling = false;
@@ -344,7 +386,8 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
     if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&idx->stream_kw, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_inputs, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&idx->ev_kw_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&idx->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_q, hipEventDisableTiming) != hipSuccess) {
         orr_index_destroy(idx);
         return fail(ORR_EDEVICE, "cannot create streams on device %d", cfg->device);
     }
@@ -374,10 +417,17 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_clen) (void)hipFree(idx->d_clen);
     if (idx->d_pool) (void)hipFree(idx->d_pool);
     if (idx->d_norm_b) (void)hipFree(idx->d_norm_b);
-    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_matches, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc,
-                      &idx->ws_terms, &idx->ws_term_pool, &idx->ws_qoff, &idx->ws_keys_a, &idx->ws_keys_b,
-                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start};
+    if (idx->d_vpool) (void)hipFree(idx->d_vpool);
+    if (idx->d_vstart) (void)hipFree(idx->d_vstart);
+    if (idx->d_vlen) (void)hipFree(idx->d_vlen);
+    if (idx->d_post_off) (void)hipFree(idx->d_post_off);
+    if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
+    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
+                      &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
+    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release();
+    if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
 }
@@ -528,6 +578,38 @@ int orr_index_seal(orr_index *idx)
     idx->h_cprefix.assign((size_t)n + 1, 0);
     for (int64_t p = 0; p < n; ++p) idx->h_cprefix[p + 1] = idx->h_cprefix[p] + idx->h_clen[p];
 
+    // token index: content goes to the host once, comes back as vocabulary + postings,
+    // and the raw text leaves HBM
+    if (n > 0) {
+        std::vector<uint8_t> h_pool((size_t)idx->pool_len + 16);
+        std::vector<uint64_t> h_cstart((size_t)n);
+        if (idx->pool_len) HIP_TRY(hipMemcpy(h_pool.data(), idx->d_pool, (size_t)idx->pool_len, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_cstart.data(), idx->d_cstart, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost));
+        orr::TokenIndexHost ti;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        orr::build_token_index(h_pool.data(), h_cstart.data(), idx->h_clen.data(), n, (int)std::min(hw, 32u), ti);
+        idx->n_tokens = (int64_t)ti.vstart.size();
+        idx->n_postings = ti.post_rows.size();
+        ORR_TRY(dev_alloc(&idx->d_vpool, ti.vpool.size() + orr::kScanPoolSlack));
+        ORR_TRY(dev_alloc(&idx->d_vstart, ti.vstart.size()));
+        ORR_TRY(dev_alloc(&idx->d_vlen, ti.vlen.size()));
+        ORR_TRY(dev_alloc(&idx->d_post_off, ti.post_off.size()));
+        ORR_TRY(dev_alloc(&idx->d_post_rows, ti.post_rows.size()));
+        HIP_TRY(hipMemsetAsync(idx->d_vpool, 0x20, ti.vpool.size() + orr::kScanPoolSlack, idx->stream));
+        if (!ti.vpool.empty()) HIP_TRY(hipMemcpyAsync(idx->d_vpool, ti.vpool.data(), ti.vpool.size(), hipMemcpyHostToDevice, idx->stream));
+        if (idx->n_tokens) {
+            HIP_TRY(hipMemcpyAsync(idx->d_vstart, ti.vstart.data(), sizeof(uint64_t) * ti.vstart.size(), hipMemcpyHostToDevice, idx->stream));
+            HIP_TRY(hipMemcpyAsync(idx->d_vlen, ti.vlen.data(), sizeof(uint32_t) * ti.vlen.size(), hipMemcpyHostToDevice, idx->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(idx->d_post_off, ti.post_off.data(), sizeof(uint64_t) * ti.post_off.size(), hipMemcpyHostToDevice, idx->stream));
+        if (idx->n_postings)
+            HIP_TRY(hipMemcpyAsync(idx->d_post_rows, ti.post_rows.data(), sizeof(uint32_t) * ti.post_rows.size(), hipMemcpyHostToDevice, idx->stream));
+        HIP_TRY(hipStreamSynchronize(idx->stream));
+        (void)hipFree(idx->d_pool); idx->d_pool = nullptr; idx->pool_cap = 0;
+        (void)hipFree(idx->d_cstart); idx->d_cstart = nullptr;
+        (void)hipFree(idx->d_clen); idx->d_clen = nullptr;
+    }
+
     // K0: exact row norms, sum_i (double)fl32(e_i*e_i) (RecallSearchService.cs:81)
     ORR_TRY(dev_alloc(&idx->d_norm_b, (size_t)std::max<int64_t>(n, 1)));
     if (idx->dim > 0 && n > 0) {
@@ -599,161 +681,225 @@ int64_t participating_rows(const orr_index *idx, int64_t candidate_limit)
     return std::max<int64_t>(0, std::min<int64_t>(local, idx->n_rows));
 }
 
-// Device side of one batch: exact dots, keyword matches, fused scores, selection.
-// Leaves [B][kprime+1] records in idx->ws_cand.  Caller holds the lock.
-int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, std::vector<float> *q_host_out)
+bool is_device_pointer(const void *p)
+{
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();            // plain malloc'd memory: not known to the runtime
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice;
+}
+
+// Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
+// Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
+// and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
+// the query vectors in host memory (valid until the next call).  Caller holds the lock.
+int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
+              const orr_candidate **recs_host)
 {
     ORR_TRY(bind_device(idx));
     const int64_t n = participating_rows(idx, a.candidate_limit);
     const int32_t B = a.B;
     const bool use_cos = a.dim > 0 && a.dim == idx->dim;
     hipStream_t s = idx->stream;
+    if (q_host) *q_host = nullptr;
+    if (recs_host) *recs_host = nullptr;
 
-    // queries
-    std::vector<float> q_host;
-    if (a.dim > 0) {
-        q_host.resize((size_t)B * a.dim);
-        HIP_TRY(hipMemcpy(q_host.data(), a.q, sizeof(float) * q_host.size(), hipMemcpyDefault));
-    }
     std::vector<uint32_t> qoff((size_t)B + 1);
     memcpy(qoff.data(), a.query_term_off, sizeof(uint32_t) * ((size_t)B + 1));
-    for (int32_t b = 0; b < B; ++b)
+    for (int32_t b = 0; b < B; ++b) {
         if (qoff[b + 1] < qoff[b]) return fail(ORR_EINVAL, "query_term_off is not monotone at query %d", b);
+        if (qoff[b + 1] - qoff[b] > 65535) return fail(ORR_EINVAL, "query %d has more than 65535 terms", b);
+    }
     const uint32_t t_begin = qoff[0], t_end = qoff[B];
     const uint32_t n_terms_total = t_end - t_begin;
     if (n_terms_total > 0 && (!a.term_off || !a.terms_utf8)) return fail(ORR_EINVAL, "terms are referenced but term_off/terms_utf8 is NULL");
 
-    std::vector<orr::QueryConst> qc((size_t)B);
-    for (int32_t b = 0; b < B; ++b) {
-        qc[b].use_cos = use_cos ? 1 : 0;
-        qc[b].norm_a = use_cos ? exact_norm(q_host.data() + (size_t)b * a.dim, a.dim) : 0.0;
-        qc[b].n_terms = (int32_t)(qoff[b + 1] - qoff[b]);
-        if (qc[b].n_terms > 65535) return fail(ORR_EINVAL, "query %d has more than 65535 terms", b);
+    // ---- record destination
+    const size_t rec_count = (size_t)B * ((size_t)kprime + 1);
+    const size_t rec_bytes = sizeof(orr_candidate) * rec_count;
+    const bool direct_host = host_records && rec_bytes <= (256u << 10);
+    orr_candidate *d_cand = nullptr;
+    if (direct_host) {
+        ORR_TRY(idx->pin_cand.reserve(rec_bytes));
+        d_cand = idx->pin_cand.as<orr_candidate>();        // pinned host memory is device-writable
+    } else {
+        ORR_TRY(idx->ws_cand.reserve(rec_bytes));
+        d_cand = idx->ws_cand.as<orr_candidate>();
     }
-    ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
-    HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc.data(), sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
 
-    ORR_TRY(idx->ws_cand.reserve(sizeof(orr_candidate) * (size_t)B * ((size_t)kprime + 1)));
-    orr_candidate *d_cand = idx->ws_cand.as<orr_candidate>();
+    // ---- query vectors: the dot kernel reads them where they are (device) or from one upload
+    const float *d_q = nullptr;
+    bool q_download_pending = false;
+    if (use_cos) {
+        const size_t qbytes = sizeof(float) * (size_t)B * a.dim;
+        ORR_TRY(idx->pin_q.reserve(qbytes));
+        if (is_device_pointer(a.q)) {
+            d_q = a.q;
+            HIP_TRY(hipMemcpyAsync(idx->pin_q.p, a.q, qbytes, hipMemcpyDeviceToHost, idx->stream_kw));
+            HIP_TRY(hipEventRecord(idx->ev_q, idx->stream_kw));
+            q_download_pending = true;
+        } else {
+            memcpy(idx->pin_q.p, a.q, qbytes);
+            ORR_TRY(idx->ws_q.reserve(qbytes));
+            HIP_TRY(hipMemcpyAsync(idx->ws_q.p, idx->pin_q.p, qbytes, hipMemcpyHostToDevice, s));
+            d_q = idx->ws_q.as<float>();
+        }
+        if (q_host) *q_host = idx->pin_q.as<float>();
+    }
 
     if (n == 0) {   // nothing on this shard takes part: empty records + trailers
-        std::vector<orr_candidate> empty((size_t)B * ((size_t)kprime + 1));
+        std::vector<orr_candidate> empty(rec_count);
         for (auto &c : empty) { memset(&c, 0, sizeof(c)); c.row_id = -1; c.order_key = -1; }
         for (int32_t b = 0; b < B; ++b) {
             orr_candidate &t = empty[(size_t)b * (kprime + 1) + kprime];
             t.approx_score = -std::numeric_limits<double>::infinity();
             t.order_key = 0; t.matches = 0; t.flags = ORR_CAND_TRAILER;
         }
-        HIP_TRY(hipMemcpyAsync(d_cand, empty.data(), sizeof(orr_candidate) * empty.size(), hipMemcpyHostToDevice, s));
+        if (direct_host) memcpy(d_cand, empty.data(), rec_bytes);
+        else HIP_TRY(hipMemcpyAsync(d_cand, empty.data(), rec_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (q_host_out) q_host_out->swap(q_host);
+        if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
+        if (recs_host && direct_host) *recs_host = d_cand;
         return ORR_OK;
     }
 
-    // K3 keyword scan
-    uint16_t *d_matches = nullptr;
-    if (n_terms_total > 0) {
-        ORR_TRY(idx->ws_matches.reserve(sizeof(uint16_t) * (size_t)B * (size_t)n));
-        d_matches = idx->ws_matches.as<uint16_t>();
-        std::vector<orr::ScanTerm> st(n_terms_total);
-        const uint32_t pool0 = a.term_off[t_begin];
-        const uint32_t pool_bytes = a.term_off[t_end] - pool0;
-        for (uint32_t t = 0; t < n_terms_total; ++t) {
-            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
-            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
-            st[t].off = o - pool0;
-            st[t].len = e - o;
-            uint32_t pre = 0, msk = 0;
-            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
-                pre |= (uint32_t)a.terms_utf8[o + k] << (8 * k);
-                msk |= 0xFFu << (8 * k);
-            }
-            st[t].prefix = pre;
-            st[t].mask = msk;
-        }
-        ORR_TRY(idx->ws_terms.reserve(sizeof(orr::ScanTerm) * st.size()));
-        ORR_TRY(idx->ws_term_pool.reserve((size_t)pool_bytes + 16));
-        ORR_TRY(idx->ws_qoff.reserve(sizeof(uint32_t) * ((size_t)B + 1 + n_terms_total)));
-        HIP_TRY(hipMemcpyAsync(idx->ws_terms.p, st.data(), sizeof(orr::ScanTerm) * st.size(), hipMemcpyHostToDevice, s));
-        if (pool_bytes)
-            HIP_TRY(hipMemcpyAsync(idx->ws_term_pool.p, a.terms_utf8 + pool0, pool_bytes, hipMemcpyHostToDevice, s));
-        // launches: groups of queries whose terms fit kMaxScanTerms; a query with more
-        // terms than that is scanned alone in slices, accumulating.
-        std::vector<uint32_t> rel;   // per-launch relative query_term_off arrays, packed
-        struct Launch { int32_t b0, nb; uint32_t t0, nt; size_t rel_at; int acc; };
-        std::vector<Launch> launches;
-        int32_t b = 0;
-        while (b < B) {
-            const uint32_t tq = qoff[b + 1] - qoff[b];
-            if (tq > (uint32_t)orr::kMaxScanTerms) {
-                for (uint32_t o = 0; o < tq; o += orr::kMaxScanTerms) {
-                    const uint32_t nt = std::min<uint32_t>(orr::kMaxScanTerms, tq - o);
-                    Launch L{b, 1, qoff[b] - t_begin + o, nt, rel.size(), o > 0};
-                    rel.push_back(0); rel.push_back(nt);
-                    launches.push_back(L);
-                }
-                ++b;
-                continue;
-            }
-            int32_t e = b;
-            uint32_t nt = 0;
-            while (e < B && e - b < 64 && (qoff[e + 1] - qoff[e]) <= (uint32_t)orr::kMaxScanTerms &&
-                   nt + (qoff[e + 1] - qoff[e]) <= (uint32_t)orr::kMaxScanTerms) {
-                nt += qoff[e + 1] - qoff[e];
-                ++e;
-            }
-            Launch L{b, e - b, qoff[b] - t_begin, nt, rel.size(), 0};
-            for (int32_t i = b; i <= e; ++i) rel.push_back(qoff[i] - qoff[b]);
-            launches.push_back(L);
-            b = e;
-        }
-        ORR_TRY(idx->ws_qoff.reserve(sizeof(uint32_t) * rel.size()));
-        HIP_TRY(hipMemcpyAsync(idx->ws_qoff.p, rel.data(), sizeof(uint32_t) * rel.size(), hipMemcpyHostToDevice, s));
-        const double content_bytes = (double)idx->h_cprefix[n];
-        // the scan runs on its own stream beside the HBM-bound dot kernel
-        HIP_TRY(hipEventRecord(idx->ev_inputs, s));
-        HIP_TRY(hipStreamWaitEvent(idx->stream_kw, idx->ev_inputs, 0));
-        for (const auto &L : launches) {
-            Timed t(idx, "keyword_scan", content_bytes + 12.0 * (double)n + 2.0 * L.nb * (double)n, idx->stream_kw);
-            HIP_TRY(orr::launch_keyword_scan(idx->d_pool, idx->d_cstart, idx->d_clen, n, idx->ws_term_pool.as<uint8_t>(),
-                                             idx->ws_terms.as<orr::ScanTerm>() + L.t0, (int32_t)L.nt,
-                                             idx->ws_qoff.as<uint32_t>() + L.rel_at, L.nb,
-                                             d_matches + (size_t)L.b0 * n, n, L.acc, idx->stream_kw));
-        }
-        HIP_TRY(hipEventRecord(idx->ev_kw_done, idx->stream_kw));
-    }
-
-    // K1e exact dots, kMaxExactQ queries per launch
+    // ---- K1e exact dots first: the long HBM-bound kernel starts before any other host work
     double *d_dot = nullptr;
     if (use_cos) {
-        ORR_TRY(idx->ws_q.reserve(sizeof(float) * (size_t)B * a.dim));
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
-        HIP_TRY(hipMemcpyAsync(idx->ws_q.p, q_host.data(), sizeof(float) * q_host.size(), hipMemcpyHostToDevice, s));
         d_dot = idx->ws_dot.as<double>();
         for (int32_t b0 = 0; b0 < B; b0 += orr::kMaxExactQ) {
             const int32_t nq = std::min<int32_t>(orr::kMaxExactQ, B - b0);
             Timed t(idx, "dot_exact", 4.0 * (double)n * idx->dim + 4.0 * nq * idx->dim + 8.0 * nq * (double)n);
-            HIP_TRY(orr::launch_dot_exact(idx->d_emb, n, idx->dim, idx->ws_q.as<float>() + (size_t)b0 * a.dim, nq, false,
+            HIP_TRY(orr::launch_dot_exact(idx->d_emb, n, idx->dim, d_q + (size_t)b0 * a.dim, nq, false,
                                           d_dot + (size_t)b0 * n, n, s));
         }
     }
 
+    // ---- K3 keyword side on its own stream: distinct terms -> vocabulary scan -> posting lists
+    // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
+    orr::KwView kw{nullptr, 0, nullptr, nullptr};
+    bool kw_overflow_possible = false;
+    uint32_t kw_max_hits = 0;
+    if (n_terms_total > 0) {
+        std::vector<std::string_view> dterms;
+        std::unordered_map<std::string_view, uint32_t> dmap;
+        std::vector<uint32_t> qmeta((size_t)n_terms_total + (size_t)B + 1);   // [term -> distinct idx][query offsets]
+        for (uint32_t t = 0; t < n_terms_total; ++t) {
+            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
+            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
+            std::string_view sv(reinterpret_cast<const char *>(a.terms_utf8) + o, e - o);
+            auto it = dmap.find(sv);
+            if (it == dmap.end()) {
+                it = dmap.emplace(sv, (uint32_t)dterms.size()).first;
+                dterms.push_back(sv);
+            }
+            qmeta[t] = it->second;
+        }
+        for (int32_t b = 0; b <= B; ++b) qmeta[n_terms_total + b] = qoff[b] - t_begin;
+        const uint32_t TT = (uint32_t)dterms.size();
+        size_t pool_bytes = 0;
+        for (auto &d : dterms) pool_bytes += d.size();
+        // one pinned block, one upload: [ScanTerm x TT][qmeta][iota 0..64][term bytes]
+        const size_t off_terms = 0;
+        const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
+        const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
+        const size_t off_pool = off_iota + sizeof(uint32_t) * 65;
+        const size_t meta_bytes = off_pool + pool_bytes + 16;
+        ORR_TRY(idx->pin_meta.reserve(meta_bytes));
+        ORR_TRY(idx->ws_meta.reserve(meta_bytes));
+        uint8_t *hm = idx->pin_meta.as<uint8_t>();
+        orr::ScanTerm *st = reinterpret_cast<orr::ScanTerm *>(hm + off_terms);
+        uint32_t cursor = 0;
+        for (uint32_t t = 0; t < TT; ++t) {
+            st[t].off = cursor;
+            st[t].len = (uint32_t)dterms[t].size();
+            uint32_t pre = 0, msk = 0;
+            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
+                pre |= (uint32_t)(uint8_t)dterms[t][k] << (8 * k);
+                msk |= 0xFFu << (8 * k);
+            }
+            st[t].prefix = pre;
+            st[t].mask = msk;
+            memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
+            cursor += st[t].len;
+        }
+        memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
+        uint32_t *iota = reinterpret_cast<uint32_t *>(hm + off_iota);
+        for (uint32_t i = 0; i < 65; ++i) iota[i] = i;
+
+        const int64_t V = idx->n_tokens;
+        const int64_t words = (idx->n_rows + 31) / 32;
+        const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
+        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, 16u << 20);
+        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(V, 1)));
+        ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
+        ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
+        ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
+        hipStream_t k = idx->stream_kw;
+        uint8_t *dm = idx->ws_meta.as<uint8_t>();
+        HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
+        HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, sizeof(uint32_t) * (size_t)TT * (size_t)words, k));
+        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
+        if (V > 0) {
+            const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
+            for (uint32_t t0 = 0; t0 < TT; t0 += orr::kMaxScanTerms) {      // every distinct term is its own 1-term "query"
+                const int32_t nt = (int32_t)std::min<uint32_t>(orr::kMaxScanTerms, TT - t0);
+                Timed t(idx, "vocab_scan", 0.0, k);
+                HIP_TRY(orr::launch_keyword_scan(idx->d_vpool, idx->d_vstart, idx->d_vlen, V, dm + off_pool, d_terms + t0, nt,
+                                                 reinterpret_cast<const uint32_t *>(dm + off_iota), nt,
+                                                 idx->ws_vmatch.as<uint16_t>() + (size_t)t0 * V, V, 0, k));
+            }
+            {
+                Timed t(idx, "vocab_hits", 0.0, k);
+                HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), V, (int32_t)TT, idx->d_post_off,
+                                               idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+            }
+            {
+                Timed t(idx, "expand_hits", 0.0, k);
+                HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
+                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k));
+            }
+        }
+        HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
+        kw.bitmaps = idx->ws_bitmaps.as<uint32_t>();
+        kw.words_per_term = words;
+        kw.q_term_idx = reinterpret_cast<const uint32_t *>(dm + off_qmeta);
+        kw.q_term_off = kw.q_term_idx + n_terms_total;
+        kw_overflow_possible = want_hits > (uint64_t)max_hits;
+        kw_max_hits = max_hits;
+    }
+
+    // ---- per-query constants (exact normA needs the vectors on the host)
+    if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
+    ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
+    ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
+    orr::QueryConst *qc = idx->pin_qc.as<orr::QueryConst>();
+    for (int32_t b = 0; b < B; ++b) {
+        qc[b].use_cos = use_cos ? 1 : 0;
+        qc[b].norm_a = use_cos ? exact_norm(idx->pin_q.as<float>() + (size_t)b * a.dim, a.dim) : 0.0;
+        qc[b].n_terms = (int32_t)(qoff[b + 1] - qoff[b]);
+    }
+    HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
     if (n_terms_total > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_kw_done, 0));
 
-    // K4/K5 fused score + selection
+    // ---- K4/K5 fused score + selection
     if (kprime <= orr::kSelWidth) {
         const int64_t n_seg = (n + orr::kSelSegRows - 1) / orr::kSelSegRows;
         ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)n_seg * orr::kSelWidth));
         {
-            Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0 + 2.0));
-            HIP_TRY(orr::launch_fuse_select(d_dot, n, idx->d_norm_b, idx->d_created, d_matches, n,
+            Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0));
+            HIP_TRY(orr::launch_fuse_select(d_dot, n, idx->d_norm_b, idx->d_created, kw,
                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B,
                                             idx->ws_sel.as<orr::SelEntry>(), s));
         }
         {
             Timed t(idx, "select_final", (double)B * (double)n_seg * orr::kSelWidth * sizeof(orr::SelEntry));
             HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), (int32_t)n_seg, B, kprime, n, idx->row_base,
-                                             d_dot, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, d_matches, n, 1,
+                                             d_dot, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw, 1,
                                              d_cand, s));
         }
     } else {
@@ -769,10 +915,9 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, std::vector<fl
         ORR_TRY(idx->ws_sort_tmp.reserve(tmp_bytes));
         for (int32_t b = 0; b < B; ++b) {
             const double *dq = d_dot ? d_dot + (size_t)b * n : nullptr;
-            const uint16_t *mq = d_matches ? d_matches + (size_t)b * n : nullptr;
             {
-                Timed t(idx, "score_keys", (double)n * 38.0);
-                HIP_TRY(orr::launch_score_keys(dq, idx->d_norm_b, idx->d_created, mq, qc[b], a.now_ticks, n,
+                Timed t(idx, "score_keys", (double)n * 36.0);
+                HIP_TRY(orr::launch_score_keys(dq, idx->d_norm_b, idx->d_created, kw, b, qc[b], a.now_ticks, n,
                                                idx->ws_keys_a.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(), s));
             }
             {
@@ -783,13 +928,20 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, std::vector<fl
                                              idx->ws_vals_b.as<uint32_t>(), n, s));
             }
             HIP_TRY(orr::launch_records_from_sorted(idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_b.as<uint32_t>(),
-                                                    kprime, n, idx->row_base, dq, idx->d_norm_b, idx->d_created,
-                                                    idx->d_row_ids, mq, 1, d_cand + (size_t)b * (kprime + 1), s));
+                                                    kprime, n, idx->row_base, d_dot, n, idx->d_norm_b, idx->d_created,
+                                                    idx->d_row_ids, kw, b, 1, d_cand + (size_t)b * (kprime + 1), s));
         }
     }
     HIP_TRY(hipStreamSynchronize(s));
     collect_events(idx);
-    if (q_host_out) q_host_out->swap(q_host);
+    if (kw_overflow_possible) {
+        unsigned long long cnt = 0;
+        HIP_TRY(hipMemcpy(&cnt, idx->ws_counter.p, sizeof(cnt), hipMemcpyDeviceToHost));
+        if ((uint32_t)(cnt >> 32) > kw_max_hits)
+            return fail(ORR_ENOMEM, "keyword terms matched %u vocabulary tokens, more than the %u-entry hit list holds",
+                        (uint32_t)(cnt >> 32), kw_max_hits);
+    }
+    if (recs_host && direct_host) *recs_host = d_cand;
     return ORR_OK;
 }
 
@@ -886,7 +1038,7 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
     std::lock_guard<std::mutex> lock(idx->mu);
-    ORR_TRY(run_shard(idx, a, kprime, nullptr));
+    ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
     HIP_TRY(hipMemcpy(out, idx->ws_cand.p, sizeof(orr_candidate) * (size_t)B * ((size_t)kprime + 1), hipMemcpyDefault));
     return ORR_OK;
 }
@@ -921,12 +1073,17 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     int64_t kprime = std::min<int64_t>(std::max<int64_t>(1, n), std::max<int64_t>((int64_t)take + 22, 32));
     if (kprime > orr::kSelWidth && take + 8 <= orr::kSelWidth) kprime = orr::kSelWidth;
     for (;;) {
-        std::vector<float> q_host;
-        ORR_TRY(run_shard(idx, a, (int32_t)kprime, &q_host));
-        std::vector<orr_candidate> recs((size_t)B * ((size_t)kprime + 1));
-        HIP_TRY(hipMemcpy(recs.data(), idx->ws_cand.p, sizeof(orr_candidate) * recs.size(), hipMemcpyDeviceToHost));
+        const float *q_host = nullptr;
+        const orr_candidate *recs = nullptr;
+        ORR_TRY(run_shard(idx, a, (int32_t)kprime, true, &q_host, &recs));
+        std::vector<orr_candidate> copied;
+        if (!recs) {                                  // large record sets stay on the device until here
+            copied.resize((size_t)B * ((size_t)kprime + 1));
+            HIP_TRY(hipMemcpy(copied.data(), idx->ws_cand.p, sizeof(orr_candidate) * copied.size(), hipMemcpyDeviceToHost));
+            recs = copied.data();
+        }
         int32_t unc = 0;
-        ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs.data(), dim, use_cos, q_host.data(), query_term_off, now_ticks,
+        ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, query_term_off, now_ticks,
                            topk, out_rows, out_scores, out_counts, &unc));
         if (unc == 0 || kprime >= n) return ORR_OK;
         kprime = std::min<int64_t>(n, kprime * 4);

@@ -51,6 +51,29 @@ hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *cstart, cons
                                const uint32_t *q_term_off, int32_t B, uint16_t *matches,
                                int64_t matches_stride, int32_t accumulate, hipStream_t s);
 
+// Keyword side of a batch as the scoring kernels see it: one row bitmap per DISTINCT
+// query term (bit r of bitmaps[t*words_per_term + r/32] = term t occurs in row r) and
+// each query's list of distinct-term indices.  bitmaps == nullptr: no query has terms.
+struct KwView {
+    const uint32_t *bitmaps;
+    int64_t words_per_term;
+    const uint32_t *q_term_idx;    // [sum of query term counts]
+    const uint32_t *q_term_off;    // [B+1]
+};
+
+// One (term, token) match: the token's posting run and where its 1024-posting chunks start.
+struct KwHit {
+    uint64_t post_begin, post_end;
+    uint32_t chunk_base;
+    uint32_t term;
+};
+constexpr uint32_t kPostChunk = 1024;
+
+hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n_terms, const uint64_t *post_off,
+                             unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
+hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
+                              const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s);
+
 // Per-query constants of the fused score.
 struct QueryConst {
     double norm_a;        // exact sum_i (double)fl32(q_i^2); unused when use_cos == 0
@@ -62,7 +85,7 @@ struct QueryConst {
 //   score = (cos*0.7) + (kw*0.2) + (rec*0.1)  in fp64, left to right (…cs:66)
 // out_sel: [B][n_seg][kSelWidth] entries, best first.  n_seg = ceil(n_rows / kSelSegRows).
 hipError_t launch_fuse_select(const double *dot, int64_t dot_stride, const double *norm_b,
-                              const int64_t *created, const uint16_t *matches, int64_t matches_stride,
+                              const int64_t *created, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               SelEntry *out_sel, hipStream_t s);
 
@@ -71,12 +94,11 @@ hipError_t launch_fuse_select(const double *dot, int64_t dot_stride, const doubl
 hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, int32_t kprime,
                                int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
                                const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                               const uint16_t *matches, int64_t matches_stride, int32_t dot_exact,
-                               orr_candidate *out, hipStream_t s);
+                               KwView kw, int32_t dot_exact, orr_candidate *out, hipStream_t s);
 
 // Generic path for large k: keys[r] = score key of (query b,row r), vals[r] = r.
 hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,
-                             const uint16_t *matches, QueryConst qc, int64_t now_ticks, int64_t n_rows,
+                             KwView kw, int32_t b, QueryConst qc, int64_t now_ticks, int64_t n_rows,
                              unsigned long long *keys, uint32_t *vals, hipStream_t s);
 // Device radix sort (descending, stable) of (keys, vals); temp sizing by query.
 hipError_t sort_pairs_desc(void *temp, size_t &temp_bytes, const unsigned long long *keys_in,
@@ -84,9 +106,9 @@ hipError_t sort_pairs_desc(void *temp, size_t &temp_bytes, const unsigned long l
                            int64_t n, hipStream_t s);
 // Builds candidate records for the first K sorted entries (+ trailer at index K).
 hipError_t launch_records_from_sorted(const unsigned long long *keys, const uint32_t *vals, int32_t K,
-                                      int64_t n_rows, int64_t row_base, const double *dot,
+                                      int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
                                       const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                                      const uint16_t *matches, int32_t dot_exact, orr_candidate *out,
+                                      KwView kw, int32_t b, int32_t dot_exact, orr_candidate *out,
                                       hipStream_t s);
 
 // Seal-time row permutation (dst[p] = src[perm[p]]).

@@ -56,6 +56,19 @@ __device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t
     return (cosv * 0.7) + (kw * 0.2) + (rec * 0.1);                          // :66
 }
 
+// matches of RecallSearchService.cs:111 for (query b, row): how many of the query's
+// distinct terms have their bit set in the per-term row bitmaps (see expand_hits_kernel).
+__device__ __forceinline__ uint32_t kw_matches(const KwView &kw, int b, uint32_t row)
+{
+    uint32_t m = 0;
+    const uint32_t t0 = kw.q_term_off[b], t1 = kw.q_term_off[b + 1];
+    for (uint32_t i = t0; i < t1; ++i) {
+        const uint32_t word = kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + (row >> 5)];
+        m += (word >> (row & 31)) & 1u;
+    }
+    return m;
+}
+
 // ---------------------------------------------------------------------------
 // K0 / K1e  exact dot: one row per lane, rows staged through a wave-private
 // LDS tile so that HBM reads stay coalesced (4 rows x 256 B per wave
@@ -64,7 +77,7 @@ __device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t
 // Tile: [64 rows][64 floats] = 16 KiB per wave, 16-byte chunks XOR-swizzled by
 // (row & 15) so that the 16-lane groups of ds_read_b128 hit 16 distinct slots.
 // ---------------------------------------------------------------------------
-template <int NQ, bool SELF, bool PREFETCH>
+template <int NQ, bool SELF, bool PREFETCH, bool NT>
 __global__ __launch_bounds__(256) void dot_exact_tiled(const float *__restrict__ E, int64_t n_rows, int32_t D,
                                                        const float *__restrict__ Q, double *__restrict__ out,
                                                        int64_t out_stride)
@@ -90,8 +103,16 @@ __global__ __launch_bounds__(256) void dot_exact_tiled(const float *__restrict__
                 const int r = it * 4 + ld_row;
                 const int64_t row = row0 + r;
                 st[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < n_rows)
-                    st[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
+                if (row < n_rows) {
+                    const float *src = E + row * (int64_t)D + c0 + ld_ch * 4;
+                    if (NT) {   // streamed once: keep it out of the caches
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
+                        st[it] = make_float4(v.x, v.y, v.z, v.w);
+                    } else {
+                        st[it] = *reinterpret_cast<const float4 *>(src);
+                    }
+                }
             }
         };
         float4 stage[16];
@@ -180,16 +201,18 @@ hipError_t launch_dot_exact(const float *E, int64_t n_rows, int32_t D, const flo
     }
     const int64_t n_groups = (n_rows + 63) / 64;
     int64_t blocks = (n_groups + 3) / 4;
-    static const int variant = [] { const char *e = getenv("ORR_DOT_VARIANT"); return e ? atoi(e) : 1; }();
-    static const int wg_per_cu = [] { const char *e = getenv("ORR_DOT_WG_PER_CU"); return e ? atoi(e) : 8; }();
+    static const int variant = [] { const char *e = getenv("ORR_DOT_VARIANT"); return e ? atoi(e) : 2; }();
+    static const int wg_per_cu = [] { const char *e = getenv("ORR_DOT_WG_PER_CU"); return e ? atoi(e) : 16; }();
     if (blocks > 256 * (int64_t)wg_per_cu) blocks = 256 * (int64_t)wg_per_cu;   // grid-stride beyond that
     dim3 grid((unsigned)blocks), block(256);
 #define ORR_LAUNCH_DOT(NQ_, SELF_)                                                                                    \
     do {                                                                                                              \
         if (variant == 0)                                                                                             \
-            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); \
+            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, false, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); \
+        else if (variant == 1)                                                                                        \
+            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);  \
         else                                                                                                          \
-            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);  \
+            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true, true>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);   \
     } while (0)
     if (self_norm) {
         ORR_LAUNCH_DOT(1, true);
@@ -324,6 +347,89 @@ hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *cstart, cons
 }
 
 // ---------------------------------------------------------------------------
+// Token index, query side.  The scan kernel above is run over the VOCABULARY
+// (one "row" per distinct token of the shard) with one single-term "query" per
+// distinct query term: vmatch[t][v] = 1 iff term t occurs inside token v.  A
+// whitespace-free term occurs in a row's content iff it occurs inside one of the
+// row's whitespace-delimited tokens, so OR-ing the posting lists of the matching
+// tokens gives exactly `contentLower.Contains(term)` (RecallSearchService.cs:111)
+// for every row.
+//
+// vocab_hits: one thread per (token, term); every hit reserves its slot in the hit
+// list and its run of 1024-posting chunks with ONE 64-bit atomic (count in the high
+// word, chunks in the low word), so hit order and chunk order agree.
+// expand_hits: grid-stride over chunks; binary search for the owning hit, then 64
+// postings per step, one atomicOr each into the term's row bitmap.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vocab_hits_kernel(const uint16_t *__restrict__ vmatch, int64_t n_tokens,
+                                                         int32_t n_terms, const uint64_t *__restrict__ post_off,
+                                                         unsigned long long *__restrict__ counter,
+                                                         KwHit *__restrict__ hits, uint32_t max_hits)
+{
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_tokens) return;
+    for (int t = 0; t < n_terms; ++t) {
+        if (vmatch[(int64_t)t * n_tokens + v] == 0) continue;
+        const uint64_t p0 = post_off[v], p1 = post_off[v + 1];
+        const uint32_t chunks = (uint32_t)((p1 - p0 + kPostChunk - 1) / kPostChunk);
+        const unsigned long long old = atomicAdd(counter, (1ull << 32) | chunks);
+        const uint32_t slot = (uint32_t)(old >> 32);
+        if (slot < max_hits) {
+            KwHit h;
+            h.post_begin = p0; h.post_end = p1; h.chunk_base = (uint32_t)old; h.term = (uint32_t)t;
+            hits[slot] = h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restrict__ hits,
+                                                          const unsigned long long *__restrict__ counter,
+                                                          uint32_t max_hits, const uint32_t *__restrict__ post_rows,
+                                                          uint32_t *__restrict__ bitmaps, int64_t words_per_term)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long cnt = *counter;
+    uint32_t n_hits = (uint32_t)(cnt >> 32);
+    if (n_hits > max_hits) n_hits = max_hits;       // overflow is detected and retried by the host
+    const uint32_t n_chunks = (uint32_t)cnt;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t c = wave_id; c < n_chunks; c += n_waves) {
+        uint32_t lo = 0, hi = n_hits;                // last hit with chunk_base <= c
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (hits[mid].chunk_base <= c) lo = mid; else hi = mid;
+        }
+        const KwHit h = hits[lo];
+        const uint64_t b0 = h.post_begin + (uint64_t)(c - h.chunk_base) * kPostChunk;
+        const uint64_t b1 = b0 + kPostChunk < h.post_end ? b0 + kPostChunk : h.post_end;
+        uint32_t *bm = bitmaps + (int64_t)h.term * words_per_term;
+        for (uint64_t p = b0 + lane; p < b1; p += 64) {
+            const uint32_t row = post_rows[p];
+            atomicOr(&bm[row >> 5], 1u << (row & 31));
+        }
+    }
+}
+
+hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n_terms, const uint64_t *post_off,
+                             unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s)
+{
+    if (n_tokens <= 0 || n_terms <= 0) return hipSuccess;
+    const int64_t blocks = (n_tokens + 255) / 256;
+    hipLaunchKernelGGL(vocab_hits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vmatch, n_tokens, n_terms, post_off,
+                       counter, hits, max_hits);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
+                              const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s)
+{
+    hipLaunchKernelGGL(expand_hits_kernel, dim3(1024), dim3(256), 0, s, hits, counter, max_hits, post_rows, bitmaps,
+                       words_per_term);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Wave-resident top-64 list: lane i holds the i-th best entry (best first).
 // "better" = larger key, then smaller candidate position (stable order).
 // ---------------------------------------------------------------------------
@@ -377,15 +483,14 @@ __device__ __forceinline__ void wave_merge_sorted(unsigned long long &k, uint32_
 // (lane = row, coalesced 8-byte reads), skips batches that cannot enter its
 // list, and the four lists are merged through LDS at the end.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fuse_select_kernel(const double *__restrict__ dot, int64_t dot_stride,
-                                                          const double *__restrict__ norm_b,
-                                                          const int64_t *__restrict__ created,
-                                                          const uint16_t *__restrict__ matches,
-                                                          int64_t matches_stride, const QueryConst *__restrict__ qcs,
-                                                          int64_t now_ticks, int64_t n_rows,
-                                                          SelEntry *__restrict__ out_sel)
+__global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restrict__ dot, int64_t dot_stride,
+                                                           const double *__restrict__ norm_b,
+                                                           const int64_t *__restrict__ created, KwView kw,
+                                                           const QueryConst *__restrict__ qcs,
+                                                           int64_t now_ticks, int64_t n_rows,
+                                                           SelEntry *__restrict__ out_sel)
 {
-    __shared__ SelEntry lists[4][kSelWidth];
+    __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -393,40 +498,50 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const double *__restri
     const int64_t seg0 = (int64_t)blockIdx.x * kSelSegRows;
     const int64_t seg1 = (seg0 + kSelSegRows < n_rows) ? seg0 + kSelSegRows : n_rows;
 
+    // each of the 16 waves scores kSelSegRows/16 = 256 rows: 4 batches of 64 whose loads are
+    // all issued before the first use
+    constexpr int U = kSelSegRows / (16 * 64);
     unsigned long long k = 0ull;
     uint32_t p = 0xFFFFFFFFu;
-    constexpr int U = 4;     // batches scored together so that their loads are in flight at once
-    for (int64_t base = seg0 + wave * 64; base < seg1; base += 256 * U) {
-        unsigned long long nk[U];
-        uint32_t np[U];
+    unsigned long long nk[U];
+    uint32_t np[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = base + 256 * u + lane;
-            nk[u] = 0ull;
-            np[u] = 0xFFFFFFFFu;
-            if (r < seg1) {
-                const double d = qc.use_cos ? dot[(int64_t)b * dot_stride + r] : 0.0;
-                const uint32_t m = qc.n_terms > 0 ? matches[(int64_t)b * matches_stride + r] : 0u;
-                nk[u] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
-                np[u] = (uint32_t)r;
-            }
+    for (int u = 0; u < U; ++u) {
+        const int64_t r = seg0 + (int64_t)(wave * U + u) * 64 + lane;
+        nk[u] = 0ull;
+        np[u] = 0xFFFFFFFFu;
+        if (r < seg1) {
+            const double d = qc.use_cos ? dot[(int64_t)b * dot_stride + r] : 0.0;
+            const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)r) : 0u;
+            nk[u] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
+            np[u] = (uint32_t)r;
         }
+    }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (base + 256 * u >= seg1) break;
+    for (int u = 0; u < U; ++u) {
+        if (seg0 + (int64_t)(wave * U + u) * 64 >= seg1) break;
+        if (u > 0) {
             const unsigned long long tk = __shfl(k, 63, 64);
             const uint32_t tp = __shfl(p, 63, 64);
             if (!__any(better(nk[u], np[u], tk, tp))) continue;
-            wave_sort(nk[u], np[u], lane);
-            wave_merge_sorted(k, p, nk[u], np[u], lane);
         }
+        wave_sort(nk[u], np[u], lane);
+        if (u == 0) { k = nk[0]; p = np[0]; }
+        else wave_merge_sorted(k, p, nk[u], np[u], lane);
     }
     lists[wave][lane].key = k;
     lists[wave][lane].pos = p;
     __syncthreads();
-    if (wave == 0) {
 #pragma unroll
-        for (int w = 1; w < 4; ++w) wave_merge_sorted(k, p, lists[w][lane].key, lists[w][lane].pos, lane);
+    for (int stride = 8; stride > 0; stride >>= 1) {
+        if (wave < stride) {
+            wave_merge_sorted(k, p, lists[wave + stride][lane].key, lists[wave + stride][lane].pos, lane);
+            lists[wave][lane].key = k;
+            lists[wave][lane].pos = p;
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
         SelEntry e;
         e.key = k; e.pos = p; e.pad = 0;
         out_sel[((int64_t)b * gridDim.x + blockIdx.x) * kSelWidth + lane] = e;
@@ -434,21 +549,21 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const double *__restri
 }
 
 hipError_t launch_fuse_select(const double *dot, int64_t dot_stride, const double *norm_b,
-                              const int64_t *created, const uint16_t *matches, int64_t matches_stride,
+                              const int64_t *created, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               SelEntry *out_sel, hipStream_t s)
 {
     if (n_rows <= 0 || B <= 0) return hipSuccess;
     const int64_t n_seg = (n_rows + kSelSegRows - 1) / kSelSegRows;
-    hipLaunchKernelGGL(fuse_select_kernel, dim3((unsigned)n_seg, (unsigned)B), dim3(256), 0, s, dot, dot_stride,
-                       norm_b, created, matches, matches_stride, qc, now_ticks, n_rows, out_sel);
+    hipLaunchKernelGGL(fuse_select_kernel, dim3((unsigned)n_seg, (unsigned)B), dim3(1024), 0, s, dot, dot_stride,
+                       norm_b, created, kw, qc, now_ticks, n_rows, out_sel);
     return hipGetLastError();
 }
 
 __device__ __forceinline__ void write_record(orr_candidate *o, unsigned long long key, uint32_t pos, int b,
                                              int64_t row_base, const double *dot, int64_t dot_stride,
                                              const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                                             const uint16_t *matches, int64_t matches_stride, int32_t dot_exact)
+                                             const KwView &kw, int32_t dot_exact)
 {
     orr_candidate c;
     if (key == 0ull) {
@@ -461,7 +576,7 @@ __device__ __forceinline__ void write_record(orr_candidate *o, unsigned long lon
         c.created_ticks = created[pos];
         c.row_id = row_ids[pos];
         c.order_key = row_base + (int64_t)pos;
-        c.matches = matches ? (int32_t)matches[(int64_t)b * matches_stride + pos] : 0;
+        c.matches = kw.bitmaps ? (int32_t)kw_matches(kw, b, pos) : 0;
         c.flags = dot_exact ? ORR_CAND_DOT_EXACT : 0;
     }
     *o = c;
@@ -476,10 +591,8 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
                                                             const double *__restrict__ dot, int64_t dot_stride,
                                                             const double *__restrict__ norm_b,
                                                             const int64_t *__restrict__ created,
-                                                            const int64_t *__restrict__ row_ids,
-                                                            const uint16_t *__restrict__ matches,
-                                                            int64_t matches_stride, int32_t dot_exact,
-                                                            orr_candidate *__restrict__ out)
+                                                            const int64_t *__restrict__ row_ids, KwView kw,
+                                                            int32_t dot_exact, orr_candidate *__restrict__ out)
 {
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
@@ -489,7 +602,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
 
     unsigned long long k = 0ull;
     uint32_t p = 0xFFFFFFFFu;
-    constexpr int U = 4;     // lists fetched together
+    constexpr int U = 8;     // lists fetched together
     for (int sg0 = wave; sg0 < n_seg; sg0 += 16 * U) {
         SelEntry e[U];
 #pragma unroll
@@ -519,8 +632,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
     if (wave == 0) {
         orr_candidate *o = out + (int64_t)b * (kprime + 1);
         if (lane < kprime)
-            write_record(o + lane, k, p, b, row_base, dot, dot_stride, norm_b, created, row_ids, matches,
-                         matches_stride, dot_exact);
+            write_record(o + lane, k, p, b, row_base, dot, dot_stride, norm_b, created, row_ids, kw, dot_exact);
         const unsigned long long valid_mask = __ballot(k != 0ull && lane < kprime);
         const int n_valid = __popcll(valid_mask);
         const unsigned long long worst_key = __shfl(k, (n_valid > 0 ? n_valid - 1 : 0), 64);
@@ -538,13 +650,12 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
 hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, int32_t kprime,
                                int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
                                const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                               const uint16_t *matches, int64_t matches_stride, int32_t dot_exact,
-                               orr_candidate *out, hipStream_t s)
+                               KwView kw, int32_t dot_exact, orr_candidate *out, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, kprime, n_rows, row_base,
-                       dot, dot_stride, norm_b, created, row_ids, matches, matches_stride, dot_exact, out);
+                       dot, dot_stride, norm_b, created, row_ids, kw, dot_exact, out);
     return hipGetLastError();
 }
 
@@ -553,28 +664,27 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void score_keys_kernel(const double *__restrict__ dot,
                                                          const double *__restrict__ norm_b,
-                                                         const int64_t *__restrict__ created,
-                                                         const uint16_t *__restrict__ matches, QueryConst qc,
-                                                         int64_t now_ticks, int64_t n_rows,
+                                                         const int64_t *__restrict__ created, KwView kw, int32_t b,
+                                                         QueryConst qc, int64_t now_ticks, int64_t n_rows,
                                                          unsigned long long *__restrict__ keys,
                                                          uint32_t *__restrict__ vals)
 {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
         const double d = qc.use_cos ? dot[r] : 0.0;
-        const uint32_t m = qc.n_terms > 0 ? matches[r] : 0u;
+        const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)r) : 0u;
         keys[r] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
         vals[r] = (uint32_t)r;
     }
 }
 
 hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,
-                             const uint16_t *matches, QueryConst qc, int64_t now_ticks, int64_t n_rows,
+                             KwView kw, int32_t b, QueryConst qc, int64_t now_ticks, int64_t n_rows,
                              unsigned long long *keys, uint32_t *vals, hipStream_t s)
 {
     if (n_rows <= 0) return hipSuccess;
     int64_t blocks = (n_rows + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(score_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dot, norm_b, created, matches, qc,
+    hipLaunchKernelGGL(score_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dot, norm_b, created, kw, b, qc,
                        now_ticks, n_rows, keys, vals);
     return hipGetLastError();
 }
@@ -590,19 +700,19 @@ hipError_t sort_pairs_desc(void *temp, size_t &temp_bytes, const unsigned long l
 __global__ __launch_bounds__(256) void records_from_sorted_kernel(const unsigned long long *__restrict__ keys,
                                                                   const uint32_t *__restrict__ vals, int32_t K,
                                                                   int64_t n_rows, int64_t row_base,
-                                                                  const double *__restrict__ dot,
+                                                                  const double *__restrict__ dot, int64_t dot_stride,
                                                                   const double *__restrict__ norm_b,
                                                                   const int64_t *__restrict__ created,
-                                                                  const int64_t *__restrict__ row_ids,
-                                                                  const uint16_t *__restrict__ matches,
-                                                                  int32_t dot_exact, orr_candidate *__restrict__ out)
+                                                                  const int64_t *__restrict__ row_ids, KwView kw,
+                                                                  int32_t b, int32_t dot_exact,
+                                                                  orr_candidate *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K) {
         if ((int64_t)i < n_rows)
-            write_record(out + i, keys[i], vals[i], 0, row_base, dot, 0, norm_b, created, row_ids, matches, 0, dot_exact);
+            write_record(out + i, keys[i], vals[i], b, row_base, dot, dot_stride, norm_b, created, row_ids, kw, dot_exact);
         else
-            write_record(out + i, 0ull, 0u, 0, row_base, dot, 0, norm_b, created, row_ids, matches, 0, dot_exact);
+            write_record(out + i, 0ull, 0u, b, row_base, dot, dot_stride, norm_b, created, row_ids, kw, dot_exact);
     } else if (i == K) {
         orr_candidate t;
         const int64_t n_valid = n_rows < (int64_t)K ? n_rows : (int64_t)K;
@@ -615,14 +725,14 @@ __global__ __launch_bounds__(256) void records_from_sorted_kernel(const unsigned
 }
 
 hipError_t launch_records_from_sorted(const unsigned long long *keys, const uint32_t *vals, int32_t K,
-                                      int64_t n_rows, int64_t row_base, const double *dot,
+                                      int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
                                       const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                                      const uint16_t *matches, int32_t dot_exact, orr_candidate *out,
+                                      KwView kw, int32_t b, int32_t dot_exact, orr_candidate *out,
                                       hipStream_t s)
 {
     const int blocks = (K + 1 + 255) / 256;
     hipLaunchKernelGGL(records_from_sorted_kernel, dim3(blocks), dim3(256), 0, s, keys, vals, K, n_rows, row_base, dot,
-                       norm_b, created, row_ids, matches, dot_exact, out);
+                       dot_stride, norm_b, created, row_ids, kw, b, dot_exact, out);
     return hipGetLastError();
 }
 
