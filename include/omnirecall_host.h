@@ -44,6 +44,41 @@ int64_t orrh_build_snippet(const uint8_t *content, int64_t content_len, int32_t 
 /* Math.Round(x, 4): banker's rounding of x*1e4 */
 double orrh_round4(double x);
 
+/* ---- store + service mirrors ------------------------------------------------
+ * orrh_store mirrors the parts of InMemoryIngestionStore the path touches
+ * (InMemoryIngestionStore.cs:11-25,50-76); orrh_service mirrors
+ * RecallSearchService.SearchAsync (RecallSearchService.cs:20-57) with lines :26-37
+ * replaced by orr_search_batch, and returns the /api/recall/search response body
+ * (RecallDtos.cs:3-16, camelCase) as JSON.  Enumeration order of documents is
+ * insertion order (the reference's ConcurrentDictionary order is unspecified).
+ * Status codes are those of omnirecall_hip.h; orrh_last_error() gives the text. */
+typedef struct orrh_store orrh_store;
+typedef struct orrh_service orrh_service;
+
+const char *orrh_last_error(void);
+orrh_store *orrh_store_create(void);
+void        orrh_store_destroy(orrh_store *s);
+/* UpsertDocumentAsync (:11-15) */
+int orrh_store_upsert_document(orrh_store *s, const char *id, const char *file_name, int64_t created_ticks);
+/* UpsertChunksAsync (:17-25): replaces the chunk list of chunks[0]'s document, ordered by
+ * chunk_index.  emb holds the chunks' vectors back to back; emb_len[i] = 0 means null. */
+int orrh_store_upsert_chunks(orrh_store *s, const char *document_id, int32_t n, const char *const *chunk_ids,
+                             const int32_t *chunk_index, const char *const *contents, const float *emb,
+                             const int32_t *emb_len, const int64_t *created_ticks);
+/* DeleteDocumentAsync (:50-55) */
+int orrh_store_delete_document(orrh_store *s, const char *document_id);
+int64_t orrh_store_chunk_count(const orrh_store *s);
+
+/* candidate_limit = GetRecentChunksAsync(maxCount) (300 in the reference). */
+orrh_service *orrh_service_create(orrh_store *s, int32_t device, int64_t candidate_limit);
+void          orrh_service_destroy(orrh_service *svc);
+/* SearchAsync(query, topK) with the query embedding supplied by the caller (the
+ * IEmbeddingClient result; qdim 0 = empty vector) and a frozen clock.  *out_json is
+ * malloc'd; release it with orrh_free.  A blank query is ORR_EINVAL "Query is required." */
+int  orrh_service_search_json(orrh_service *svc, const char *query_utf8, const float *qvec, int32_t qdim,
+                              int32_t topk, int64_t now_ticks, char **out_json, int64_t *out_len);
+void orrh_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

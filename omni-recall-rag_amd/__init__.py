@@ -12,6 +12,7 @@ from . import _native as native
 from ._native import OrrError
 from .index import CAND_DTYPE, RecallIndex, merge_candidates, pack_contents, pack_terms
 from . import text
+from . import service
 
-__all__ = ["native", "OrrError", "RecallIndex", "merge_candidates", "pack_contents", "pack_terms", "text",
+__all__ = ["native", "OrrError", "RecallIndex", "merge_candidates", "pack_contents", "pack_terms", "text", "service",
            "CAND_DTYPE"]

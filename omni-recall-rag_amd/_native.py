@@ -90,13 +90,37 @@ host.orrh_build_snippet.argtypes = [C.c_char_p, _i64, _i32, _vp, _i64]
 host.orrh_round4.restype = _dbl
 host.orrh_round4.argtypes = [_dbl]
 
+host.orrh_last_error.restype = C.c_char_p
+host.orrh_store_create.restype = _vp
+host.orrh_store_destroy.restype = None
+host.orrh_store_destroy.argtypes = [_vp]
+host.orrh_store_upsert_document.restype = C.c_int
+host.orrh_store_upsert_document.argtypes = [_vp, C.c_char_p, C.c_char_p, _i64]
+host.orrh_store_upsert_chunks.restype = C.c_int
+host.orrh_store_upsert_chunks.argtypes = [_vp, C.c_char_p, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
+host.orrh_store_delete_document.restype = C.c_int
+host.orrh_store_delete_document.argtypes = [_vp, C.c_char_p]
+host.orrh_store_chunk_count.restype = _i64
+host.orrh_store_chunk_count.argtypes = [_vp]
+host.orrh_service_create.restype = _vp
+host.orrh_service_create.argtypes = [_vp, _i32, _i64]
+host.orrh_service_destroy.restype = None
+host.orrh_service_destroy.argtypes = [_vp]
+host.orrh_service_search_json.restype = C.c_int
+host.orrh_service_search_json.argtypes = [_vp, C.c_char_p, _vp, _i32, _i32, _i64, C.POINTER(_vp), C.POINTER(_i64)]
+host.orrh_free.restype = None
+host.orrh_free.argtypes = [_vp]
+
 EXPORTED_HIP_SYMBOLS = [
     "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
     "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
-                         "orrh_round4"]
+                         "orrh_round4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
+                         "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
+                         "orrh_store_chunk_count", "orrh_service_create", "orrh_service_destroy",
+                         "orrh_service_search_json", "orrh_free"]
 
 
 def check(status: int) -> None:

@@ -65,7 +65,7 @@ def oracle_shard_search(P, orc, c, lo, hi):
     return search
 
 
-def run(rank, world, port, n, dim, seed, result_path):
+def run(rank, world, port, n, dim, seed, result_path, use_gpu=False):
     import torch
     import torch.distributed as dist
     import importlib
@@ -79,7 +79,12 @@ def run(rank, world, port, n, dim, seed, result_path):
     c = make_corpus(n, dim, seed)
     bounds = [n * r // world for r in range(world + 1)]
     lo, hi = bounds[rank], bounds[rank + 1]
-    front = sharded.ShardedRecallSearch(None, dim, "cpu", shard_search=oracle_shard_search(P, orc, c, lo, hi))
+    if use_gpu:      # real shards: every rank keeps its rows on cuda:0 (<= 6 processes may share the card)
+        from helpers import build_index
+        sub = {"emb": c["emb"][lo:hi], "created": c["created"][lo:hi], "contents": c["contents"][lo:hi], "dim": dim}
+        front = sharded.ShardedRecallSearch(build_index(sub, row_base=lo), dim, "cpu")
+    else:
+        front = sharded.ShardedRecallSearch(None, dim, "cpu", shard_search=oracle_shard_search(P, orc, c, lo, hi))
     rng = np.random.default_rng(100 + rank)
     B_local = 2
     results = []
@@ -101,4 +106,5 @@ def run(rank, world, port, n, dim, seed, result_path):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7],
+        use_gpu=len(sys.argv) > 8 and sys.argv[8] == "gpu")

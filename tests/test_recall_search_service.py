@@ -1,0 +1,153 @@
+"""The reference's own recall-search tests, restated against the C++ store/service mirror
+over the HIP scorer (tests/OmniRecall.Api.Tests/Services/RecallSearchServiceTests.cs:8-117,
+Endpoints/RecallEndpointTests.cs:10-30), plus response-contract checks against the oracle."""
+import numpy as np
+import pytest
+
+from helpers import has_gpu, orc, pkg
+
+NOW = 639144000000000000
+
+
+def _svc():
+    P = pkg()
+    return P.service
+
+
+def seed(store, S, now=NOW):
+    """SeedAsync, RecallSearchServiceTests.cs:51-117."""
+    for i, (fid, fname) in enumerate((("doc-1", "notes-azure.md"), ("doc-2", "notes-devops.md"), ("doc-3", "notes-common.md"))):
+        store.UpsertDocument(S.CosmosDocumentRecord(fid, fname, now))
+    store.UpsertChunks([S.CosmosChunkRecord("doc-1:0000", "doc-1", 0, "azure cosmos db vector search", [1.0, 0.0], now)])
+    store.UpsertChunks([S.CosmosChunkRecord("doc-2:0000", "doc-2", 0, "kubernetes deployment yaml and helm chart", [0.0, 1.0], now)])
+    store.UpsertChunks([S.CosmosChunkRecord("doc-3:0000", "doc-3", 0, "what is the and of for", [0.0, 0.0], now)])
+
+
+def test_blank_query_is_argument_error_without_touching_the_gpu():
+    S = _svc()
+    store = S.InMemoryIngestionStore()
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient([]), now_ticks=NOW)
+    for q in ("", "   ", "\t\n"):
+        with pytest.raises(S.HostError) as ei:
+            sut.Search(q, 3)
+        assert ei.value.code == -1 and str(ei.value) == "Query is required."        # RecallSearchService.cs:22-23
+    sut.close()
+    store.close()
+
+
+def test_store_upsert_replace_delete_counts():
+    S = _svc()
+    store = S.InMemoryIngestionStore()
+    seed(store, S)
+    assert store.ChunkCount() == 3
+    store.UpsertChunks([S.CosmosChunkRecord("doc-1:0001", "doc-1", 1, "b", None, NOW),
+                        S.CosmosChunkRecord("doc-1:0000", "doc-1", 0, "a", None, NOW)])     # replaces doc-1's list
+    assert store.ChunkCount() == 4
+    store.DeleteDocument("doc-2")
+    assert store.ChunkCount() == 3
+    store.close()
+
+
+@pytest.mark.gpu
+def test_SearchAsync_WithEmbeddings_ReturnsMostSimilarChunkFirst():
+    S = _svc()
+    store = S.InMemoryIngestionStore()
+    seed(store, S)
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient([1.0, 0.0]), now_ticks=NOW)
+    result = sut.Search("azure", 3)
+    assert result["citations"]
+    assert result["citations"][0]["documentId"] == "doc-1"
+    assert result["citations"][0]["fileName"] == "notes-azure.md"
+    assert result["citations"][0]["score"] == 1.0            # Math.Round(0.9999999999999999, 4)
+    assert [c["score"] for c in result["citations"]] == [1.0, 0.1, 0.1]
+    sut.close(); store.close()
+
+
+@pytest.mark.gpu
+def test_SearchAsync_NoQueryEmbedding_FallsBackToKeywordScore():
+    S = _svc()
+    store = S.InMemoryIngestionStore()
+    seed(store, S)
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient([]), now_ticks=NOW)
+    result = sut.Search("kubernetes", 3)
+    assert result["citations"] and result["citations"][0]["documentId"] == "doc-2"
+    assert result["citations"][0]["score"] == 0.3
+    sut.close(); store.close()
+
+
+@pytest.mark.gpu
+def test_SearchAsync_StopWordsDoNotDiluteKeywordMatch():
+    S = _svc()
+    store = S.InMemoryIngestionStore()
+    seed(store, S)
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient([]), now_ticks=NOW)
+    result = sut.Search("what is the kubernetes", 3)
+    assert result["citations"] and result["citations"][0]["documentId"] == "doc-2"
+    sut.close(); store.close()
+
+
+@pytest.mark.gpu
+def test_SearchRecall_AfterUpload_ReturnsCitations_contract():
+    """RecallEndpointTests.cs:10-30 with the NoOp embedder, and the whole response body."""
+    S = _svc()
+    store = S.InMemoryIngestionStore()
+    text = "nebula architecture notes for azure functions and angular app"
+    created = NOW - 1234567
+    store.UpsertDocument(S.CosmosDocumentRecord("d1", "nebula-notes.md", created))
+    store.UpsertChunks([S.CosmosChunkRecord("d1:0000", "d1", 0, text, None, created)])
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient([]), now_ticks=NOW)
+    body = sut.Search("nebula", 3)
+    assert body["query"] == "nebula" and len(body["citations"]) == 1
+    c = body["citations"][0]
+    assert set(c) == {"documentId", "fileName", "chunkId", "chunkIndex", "snippet", "score", "createdAtUtc"}
+    assert c["fileName"] == "nebula-notes.md" and c["chunkId"] == "d1:0000" and c["chunkIndex"] == 0
+    assert c["snippet"] == text
+    assert c["score"] == orc.round4(0.2 + orc.recency(created, NOW) * 0.1)
+    assert c["createdAtUtc"] == "2026-05-14T23:59:59.8765433Z"
+    sut.close(); store.close()
+
+
+@pytest.mark.gpu
+def test_service_matches_oracle_on_a_multi_document_store():
+    """Unknown file names, snippets cut at 180 chars, chunk-index ordering inside a document,
+    store mutation between searches, candidate_limit 300 vs all."""
+    S = _svc()
+    rng = np.random.default_rng(4)
+    store = S.InMemoryIngestionStore()
+    words = ["alpha", "beta", "Gamma", "delta", "kubernetes", "azure", "the", "of"]
+    chunks_flat = []
+    for d in range(40):
+        did = "doc-%02d" % d
+        created = NOW - int(rng.integers(0, 200)) * 864000000000 - int(rng.integers(0, 10**9))
+        if d % 5:
+            store.UpsertDocument(S.CosmosDocumentRecord(did, "file-%02d.md" % d, created))
+        cs = []
+        for i in rng.permutation(10):
+            content = " ".join(rng.choice(words, size=int(rng.integers(5, 60)))) + ("\nline two " * (i % 3))
+            cs.append(S.CosmosChunkRecord("%s:%04d" % (did, i), did, int(i), content,
+                                          rng.standard_normal(8).astype(np.float32), created))
+        store.UpsertChunks(cs)
+        chunks_flat += sorted(cs, key=lambda c: c.ChunkIndex)
+
+    def expect(chunks, qv, text, k, limit):
+        cor = orc.OracleCorpus([c.Embedding for c in chunks], [c.CreatedAtTicks for c in chunks], [c.Content for c in chunks])
+        rows, scores, rounded = cor.search(qv, text, NOW, k, candidate_limit=limit)
+        return [(chunks[r].Id, rd, orc.snippet(chunks[r].Content).decode()) for r, rd in zip(rows, rounded)]
+
+    qv = rng.standard_normal(8).astype(np.float32)
+    for limit in (300, 10**6):
+        sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=limit, now_ticks=NOW)
+        for text, k in (("alpha kubernetes", 5), ("the GAMMA", 12), ("zzz", 1)):
+            body = sut.Search(text, k)
+            got = [(c["chunkId"], c["score"], c["snippet"]) for c in body["citations"]]
+            assert got == expect(chunks_flat, qv, text, k, limit)
+            for c in body["citations"]:
+                d = int(c["documentId"][4:])
+                assert c["fileName"] == ("file-%02d.md" % d if d % 5 else "unknown")       # :47
+        store.DeleteDocument("doc-03")
+        remaining = [c for c in chunks_flat if c.DocumentId != "doc-03"]
+        body = sut.Search("alpha", 7)                                                       # index rebuilt after the change
+        assert [(c["chunkId"], c["score"], c["snippet"]) for c in body["citations"]] == expect(remaining, qv, "alpha", 7, limit)
+        chunks_flat = remaining
+        sut.close()
+    store.close()

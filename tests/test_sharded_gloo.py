@@ -19,13 +19,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_search_over_gloo(tmp_path, world):
+def _run_world(tmp_path, world, n, dim, extra=()):
     port = _free_port()
     res = str(tmp_path / "res")
     env = dict(os.environ, OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world),
-                               str(port), "240", "16", "77", res], env=env, stdout=subprocess.PIPE,
+                               str(port), str(n), str(dim), "77", res, *extra], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
@@ -39,6 +38,18 @@ def test_row_sharded_search_over_gloo(tmp_path, world):
     for r, p in enumerate(procs):
         assert p.returncode == 0, outs[r][-3000:]
         assert open(res + ".%d" % r).read() == "ok", outs[r][-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_search_over_gloo(tmp_path, world):
+    _run_world(tmp_path, world, 240, 16)
+
+
+@pytest.mark.gpu
+def test_row_sharded_search_real_shards_on_one_gpu(tmp_path):
+    """Three ranks, each with a REAL HIP shard on cuda:0 (gloo carries the exchange here; the
+    bench uses RCCL): identical to the oracle over the whole corpus, including k' escalation."""
+    _run_world(tmp_path, 3, 3000, 128, extra=("gpu",))
 
 
 def test_term_slot_roundtrip():
