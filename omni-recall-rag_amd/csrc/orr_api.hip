@@ -157,7 +157,7 @@ struct orr_index {
     bool sealed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_sel, ws_cand, ws_qc;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -422,7 +422,7 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_vlen) (void)hipFree(idx->d_vlen);
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
-    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -660,6 +660,8 @@ struct BatchArgs {
     const uint32_t *query_term_off;
     int64_t now_ticks;
     int64_t candidate_limit;
+    bool force_exact = false;      // skip the MFMA candidate pass (escalation after a failed certificate)
+    mutable bool used_mfma = false; // set by run_shard
 };
 
 int check_batch(const orr_index *idx, const BatchArgs &a, const char *fn)
@@ -720,7 +722,12 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     // ---- record destination
     const size_t rec_count = (size_t)B * ((size_t)kprime + 1);
     const size_t rec_bytes = sizeof(orr_candidate) * rec_count;
-    const bool direct_host = host_records && rec_bytes <= (256u << 10);
+    // Batched candidate pass on the matrix cores (K2) + exact re-score (K6) from this batch size
+    // up; below it the HBM-bound exact kernel is as fast and needs no second pass.
+    static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 9; }();
+    const bool use_mfma = use_cos && !a.force_exact && B >= mfma_min_batch && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
+    a.used_mfma = use_mfma;
+    const bool direct_host = host_records && !use_mfma && rec_bytes <= (256u << 10);
     orr_candidate *d_cand = nullptr;
     if (direct_host) {
         ORR_TRY(idx->pin_cand.reserve(rec_bytes));
@@ -766,9 +773,18 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         return ORR_OK;
     }
 
-    // ---- K1e exact dots first: the long HBM-bound kernel starts before any other host work
+    // ---- cosine numerators first: the long kernel starts before any other host work
     double *d_dot = nullptr;
-    if (use_cos) {
+    float *d_dotf = nullptr;
+    double approx_eps = 0.0;
+    if (use_cos && use_mfma) {
+        ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
+        d_dotf = idx->ws_dotf.as<float>();
+        Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
+        HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
+        // |fmaf chain - reference sum| <= (D+2) 2^-24 sum|q_k e_k| <= (D+2) 2^-24 |q||e|  (Cauchy-Schwarz)
+        approx_eps = 0.7 * 1.01 * (double)(idx->dim + 2) * 5.9604644775390625e-08 + 1e-12;
+    } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
         d_dot = idx->ws_dot.as<double>();
         for (int32_t b0 = 0; b0 < B; b0 += orr::kMaxExactQ) {
@@ -892,15 +908,19 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)n_seg * orr::kSelWidth));
         {
             Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0));
-            HIP_TRY(orr::launch_fuse_select(d_dot, n, idx->d_norm_b, idx->d_created, kw,
+            HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, kw,
                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B,
                                             idx->ws_sel.as<orr::SelEntry>(), s));
         }
         {
             Timed t(idx, "select_final", (double)B * (double)n_seg * orr::kSelWidth * sizeof(orr::SelEntry));
             HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), (int32_t)n_seg, B, kprime, n, idx->row_base,
-                                             d_dot, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw, 1,
-                                             d_cand, s));
+                                             d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                             use_mfma ? 0 : 1, approx_eps, d_cand, s));
+        }
+        if (use_mfma) {   // K6: the survivors' dots again, now in the reference's own arithmetic
+            Timed t(idx, "rescore_exact", (double)B * kprime * 4.0 * idx->dim);
+            HIP_TRY(orr::launch_rescore_exact(idx->d_emb, idx->dim, d_q, B, kprime, idx->row_base, d_cand, s));
         }
     } else {
         // generic large-k path: full stable sort of every score, query by query
@@ -954,6 +974,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
 {
     std::vector<Ranked> ranked;
     double cutoff = -std::numeric_limits<double>::infinity();
+    double eps = kCertifyEps;
     bool any_cut = false;
     *err = ORR_OK;
     for (int32_t sidx = 0; sidx < n_shards; ++sidx) {
@@ -972,6 +993,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
             r.row_id = c.row_id;
             ranked.push_back(r);
         }
+        if (tr.dot > eps) eps = tr.dot;            // bound of the pass that produced this shard's records
         if (tr.approx_score != -std::numeric_limits<double>::infinity()) {
             any_cut = true;
             // NaN cut-off: everything left out is NaN too (NaN sorts last), harmless
@@ -995,7 +1017,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
         *certified = false;                       // fewer results than asked while rows were cut
     } else {
         const double sk = ranked[n_out - 1].score;
-        *certified = sk > cutoff + kCertifyEps;   // false for NaN
+        *certified = sk > cutoff + eps;           // false for NaN
     }
     return n_out;
 }
@@ -1033,7 +1055,7 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
                      int64_t candidate_limit, orr_candidate *out)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, false, false};
     ORR_TRY(check_batch(idx, a, "orr_search_shard"));
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
@@ -1061,7 +1083,7 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
                      int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_counts)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, false, false};
     ORR_TRY(check_batch(idx, a, "orr_search_batch"));
     if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_search_batch: output buffers are required");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -1085,7 +1107,9 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
         int32_t unc = 0;
         ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, query_term_off, now_ticks,
                            topk, out_rows, out_scores, out_counts, &unc));
-        if (unc == 0 || kprime >= n) return ORR_OK;
+        if (unc == 0) return ORR_OK;
+        if (a.used_mfma) { a.force_exact = true; continue; }        // first retry: exact pass, same k'
+        if (kprime >= n) return ORR_OK;
         kprime = std::min<int64_t>(n, kprime * 4);
     }
 }

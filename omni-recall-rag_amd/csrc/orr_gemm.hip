@@ -1,0 +1,234 @@
+// orr_gemm.hip -- batched candidate pass (K2) and exact re-score of the survivors (K6).
+//
+// K2: approximate dots S[b][r] = sum_k Q[b][k] * E[r][k] for a whole batch on the matrix
+// cores with the f32-input MFMA v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain, so
+// |S - reference dot| <= (D+2) * 2^-24 * sum|q_k e_k|).  It only has to be good enough to
+// pick k' >= k candidates per query; K6 then recomputes the survivors' dots in the
+// reference's own arithmetic (RecallSearchService.cs:77-82) and the host certifies the
+// result against the cut-off (orr_api.hip).
+#include "orr_kernels.h"
+
+namespace orr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// K2  128 x 128 output tile per workgroup (queries x rows), BK = 64, 4 waves as 2 x 2,
+// each wave a 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).
+//
+// LDS image of an operand tile: [128 rows][2 halves][32] floats with a 68-float row
+// stride.  Half h of a row holds its k = h, h+2, h+4, ... (the 32x32x2 MFMA wants
+// A[i][k = lane>>5] and B[k = lane>>5][j] with i/j = lane & 31), so every lane reads its
+// operand values for 4 consecutive MFMAs with one ds_read_b128; the 272-byte stride puts
+// the 16 lanes of each ds_read_b128 group on 16 different 16-byte slots.
+// Global -> LDS goes through registers (the even/odd split needs it): every row piece is
+// 256 contiguous bytes, the next K-step's loads are in flight while this one is computed.
+// ---------------------------------------------------------------------------
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 64, kGemmLd = 68;
+
+__device__ __forceinline__ void stage_write(float *tile, int r, int c4, const float4 &v)
+{
+    // row r, k = 4*c4 .. 4*c4+3  ->  evens to half 0, odds to half 1, at position k/2
+    float *row = tile + r * kGemmLd;
+    *reinterpret_cast<float2 *>(row + 2 * c4) = make_float2(v.x, v.z);
+    *reinterpret_cast<float2 *>(row + 32 + 2 * c4) = make_float2(v.y, v.w);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__restrict__ Q, int32_t B,
+                                                              const float *__restrict__ E, int64_t n_rows, int32_t D,
+                                                              float *__restrict__ S, int64_t s_stride)
+{
+    __shared__ __attribute__((aligned(16))) float lds_a[kGemmBM * kGemmLd];
+    __shared__ __attribute__((aligned(16))) float lds_b[kGemmBN * kGemmLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                       // wave's 64 x 64 sub-tile
+    const int64_t n0 = (int64_t)blockIdx.x * kGemmBN;
+    const int b0 = blockIdx.y * kGemmBM;
+
+    // staging assignment: 8 loads per operand per thread; load it covers rows it*16 + tid/16,
+    // 16-byte chunk tid%16 of the 256-byte row piece
+    const int ld_r = tid >> 4, ld_c = tid & 15;
+    float4 ra[8], rb[8];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 16 + ld_r;
+            ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b0 + r < B) ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)(b0 + r) * D + k0 + ld_c * 4);
+            if (n0 + r < n_rows) {
+                const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + (n0 + r) * (int64_t)D + k0 + ld_c * 4));
+                rb[it] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const float *pa = lds_a + (wm * 64 + fr) * kGemmLd + fh * 32;
+    const float *pb = lds_b + (wn * 64 + fr) * kGemmLd + fh * 32;
+
+    load_stage(0);
+    for (int k0 = 0; k0 < D; k0 += kGemmBK) {
+        __syncthreads();                                            // previous step's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            stage_write(lds_a, it * 16 + ld_r, ld_c, ra[it]);
+            stage_write(lds_b, it * 16 + ld_r, ld_c, rb[it]);
+        }
+        if (k0 + kGemmBK < D) load_stage(k0 + kGemmBK);             // in flight during the MFMAs below
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                               // 4 k-pairs per group
+            const float4 a0 = *reinterpret_cast<const float4 *>(pa + 4 * g);
+            const float4 a1 = *reinterpret_cast<const float4 *>(pa + 32 * kGemmLd + 4 * g);
+            const float4 c0 = *reinterpret_cast<const float4 *>(pb + 4 * g);
+            const float4 c1 = *reinterpret_cast<const float4 *>(pb + 32 * kGemmLd + 4 * g);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {c0.x, c0.y, c0.z, c0.w}, bv1[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+            }
+        }
+}
+
+hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
+                               int64_t s_stride, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (D % kGemmBK != 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n_rows + kGemmBN - 1) / kGemmBN), (unsigned)((B + kGemmBM - 1) / kGemmBM));
+    hipLaunchKernelGGL(gemm_dot_f32_kernel, grid, dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K6  exact re-score: one wave per query, lane c = the query's c-th candidate record.
+// Same structure as dot_exact_tiled (rows staged through a swizzled wave-private LDS
+// tile, each lane then walks its own row in index order), with the 64 rows GATHERED by
+// the records' candidate positions.  Writes the reference-order fp64 dot into the record
+// and marks it ORR_CAND_DOT_EXACT.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rescore_exact_kernel(const float *__restrict__ E, int32_t D,
+                                                            const float *__restrict__ Q, int32_t B, int32_t kprime,
+                                                            int64_t row_base, orr_candidate *__restrict__ recs)
+{
+    __shared__ __attribute__((aligned(16))) float tile_all[4][64 * 64];
+    __shared__ int64_t rows_all[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float *tile = tile_all[wave];
+    int64_t *rows = rows_all[wave];
+    orr_candidate *mine = recs + (int64_t)b * (kprime + 1);
+    int64_t my_row = -1;
+    if (lane < kprime && mine[lane].row_id >= 0 && !(mine[lane].flags & ORR_CAND_TRAILER))
+        my_row = mine[lane].order_key - row_base;                     // position in this shard
+    rows[lane] = my_row;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ld_row = lane >> 4, ld_ch = lane & 15;
+    const float *q = Q + (int64_t)b * D;
+    double acc = 0.0;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+        float4 stage[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + ld_row;
+            const int64_t row = rows[r];
+            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0) stage[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + ld_row;
+            *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 e = *reinterpret_cast<const float4 *>(tile + lane * 64 + ((j ^ (lane & 15)) << 2));
+            const float *qp = q + c0 + j * 4;
+            float p0 = qp[0] * e.x;
+            acc += (double)p0;
+            float p1 = qp[1] * e.y;
+            acc += (double)p1;
+            float p2 = qp[2] * e.z;
+            acc += (double)p2;
+            float p3 = qp[3] * e.w;
+            acc += (double)p3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (my_row >= 0) {
+        mine[lane].dot = acc;
+        mine[lane].flags |= ORR_CAND_DOT_EXACT;
+    }
+}
+
+// any D: one thread per candidate, plain loads
+__global__ __launch_bounds__(256) void rescore_exact_generic(const float *__restrict__ E, int32_t D,
+                                                             const float *__restrict__ Q, int32_t B, int32_t kprime,
+                                                             int64_t row_base, orr_candidate *__restrict__ recs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * kprime) return;
+    const int b = (int)(t / kprime), c = (int)(t % kprime);
+    orr_candidate *r = recs + (int64_t)b * (kprime + 1) + c;
+    if (r->row_id < 0) return;
+    const float *e = E + (r->order_key - row_base) * (int64_t)D;
+    const float *q = Q + (int64_t)b * D;
+    double acc = 0.0;
+    for (int i = 0; i < D; ++i) {
+        float p = q[i] * e[i];
+        acc += (double)p;
+    }
+    r->dot = acc;
+    r->flags |= ORR_CAND_DOT_EXACT;
+}
+
+hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32_t B, int32_t kprime, int64_t row_base,
+                                orr_candidate *recs, hipStream_t s)
+{
+    if (B <= 0 || D <= 0) return hipSuccess;
+    if (kprime <= 64 && D % 64 == 0 && (reinterpret_cast<uintptr_t>(E) & 15) == 0) {
+        hipLaunchKernelGGL(rescore_exact_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, E, D, Q, B, kprime, row_base, recs);
+    } else {
+        const int64_t threads = (int64_t)B * kprime;
+        hipLaunchKernelGGL(rescore_exact_generic, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, D, Q, B, kprime,
+                           row_base, recs);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace orr

@@ -84,17 +84,30 @@ struct QueryConst {
 // K4+K5a: fused score per (query,row) and per-workgroup top-64.
 //   score = (cos*0.7) + (kw*0.2) + (rec*0.1)  in fp64, left to right (…cs:66)
 // out_sel: [B][n_seg][kSelWidth] entries, best first.  n_seg = ceil(n_rows / kSelSegRows).
-hipError_t launch_fuse_select(const double *dot, int64_t dot_stride, const double *norm_b,
+// dot (fp64, exact pass) or dotf (fp32, K2 candidate pass): exactly one is non-null when cosine applies.
+hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
                               const int64_t *created, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               SelEntry *out_sel, hipStream_t s);
 
 // K5b: merges the per-workgroup lists of each query and writes kprime candidate
 // records plus the trailer ([B][kprime+1], see orr_candidate).
+// approx_eps goes into the trailer's `dot` field: the bound on |selection score - exact score|
+// of the pass that produced the records (0 for the exact pass).
 hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, int32_t kprime,
-                               int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
-                               const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                               KwView kw, int32_t dot_exact, orr_candidate *out, hipStream_t s);
+                               int64_t n_rows, int64_t row_base, const double *dot, const float *dotf,
+                               int64_t dot_stride, const double *norm_b, const int64_t *created,
+                               const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
+                               orr_candidate *out, hipStream_t s);
+
+// K2: S[b][r] ~= sum_k Q[b][k] * E[r][k] on the matrix cores (f32-input MFMA, fmaf chain in k
+// order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
+hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
+                               int64_t s_stride, hipStream_t s);
+// K6: recomputes records[b][c].dot in the reference's exact arithmetic for every valid record
+// (row = order_key - row_base) and sets ORR_CAND_DOT_EXACT.
+hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32_t B, int32_t kprime, int64_t row_base,
+                                orr_candidate *recs, hipStream_t s);
 
 // Generic path for large k: keys[r] = score key of (query b,row r), vals[r] = r.
 hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,

@@ -483,7 +483,8 @@ __device__ __forceinline__ void wave_merge_sorted(unsigned long long &k, uint32_
 // (lane = row, coalesced 8-byte reads), skips batches that cannot enter its
 // list, and the four lists are merged through LDS at the end.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restrict__ dot, int64_t dot_stride,
+__global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restrict__ dot,
+                                                           const float *__restrict__ dotf, int64_t dot_stride,
                                                            const double *__restrict__ norm_b,
                                                            const int64_t *__restrict__ created, KwView kw,
                                                            const QueryConst *__restrict__ qcs,
@@ -511,7 +512,9 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
         nk[u] = 0ull;
         np[u] = 0xFFFFFFFFu;
         if (r < seg1) {
-            const double d = qc.use_cos ? dot[(int64_t)b * dot_stride + r] : 0.0;
+            const double d = !qc.use_cos ? 0.0
+                             : dotf  ? (double)dotf[(int64_t)b * dot_stride + r]     // K2 candidate pass
+                                     : dot[(int64_t)b * dot_stride + r];             // K1e exact
             const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)r) : 0u;
             nk[u] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
             np[u] = (uint32_t)r;
@@ -548,20 +551,20 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
     }
 }
 
-hipError_t launch_fuse_select(const double *dot, int64_t dot_stride, const double *norm_b,
+hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
                               const int64_t *created, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               SelEntry *out_sel, hipStream_t s)
 {
     if (n_rows <= 0 || B <= 0) return hipSuccess;
     const int64_t n_seg = (n_rows + kSelSegRows - 1) / kSelSegRows;
-    hipLaunchKernelGGL(fuse_select_kernel, dim3((unsigned)n_seg, (unsigned)B), dim3(1024), 0, s, dot, dot_stride,
+    hipLaunchKernelGGL(fuse_select_kernel, dim3((unsigned)n_seg, (unsigned)B), dim3(1024), 0, s, dot, dotf, dot_stride,
                        norm_b, created, kw, qc, now_ticks, n_rows, out_sel);
     return hipGetLastError();
 }
 
 __device__ __forceinline__ void write_record(orr_candidate *o, unsigned long long key, uint32_t pos, int b,
-                                             int64_t row_base, const double *dot, int64_t dot_stride,
+                                             int64_t row_base, const double *dot, const float *dotf, int64_t dot_stride,
                                              const double *norm_b, const int64_t *created, const int64_t *row_ids,
                                              const KwView &kw, int32_t dot_exact)
 {
@@ -571,7 +574,7 @@ __device__ __forceinline__ void write_record(orr_candidate *o, unsigned long lon
         c.row_id = -1; c.order_key = -1; c.matches = 0; c.flags = 0;
     } else {
         c.approx_score = key_score(key);
-        c.dot = dot ? dot[(int64_t)b * dot_stride + pos] : 0.0;
+        c.dot = dot ? dot[(int64_t)b * dot_stride + pos] : (dotf ? (double)dotf[(int64_t)b * dot_stride + pos] : 0.0);
         c.norm_b = norm_b[pos];
         c.created_ticks = created[pos];
         c.row_id = row_ids[pos];
@@ -588,11 +591,13 @@ __device__ __forceinline__ void write_record(orr_candidate *o, unsigned long lon
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__restrict__ sel, int32_t n_seg,
                                                             int32_t kprime, int64_t n_rows, int64_t row_base,
-                                                            const double *__restrict__ dot, int64_t dot_stride,
+                                                            const double *__restrict__ dot,
+                                                            const float *__restrict__ dotf, int64_t dot_stride,
                                                             const double *__restrict__ norm_b,
                                                             const int64_t *__restrict__ created,
                                                             const int64_t *__restrict__ row_ids, KwView kw,
-                                                            int32_t dot_exact, orr_candidate *__restrict__ out)
+                                                            int32_t dot_exact, double approx_eps,
+                                                            orr_candidate *__restrict__ out)
 {
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
     if (wave == 0) {
         orr_candidate *o = out + (int64_t)b * (kprime + 1);
         if (lane < kprime)
-            write_record(o + lane, k, p, b, row_base, dot, dot_stride, norm_b, created, row_ids, kw, dot_exact);
+            write_record(o + lane, k, p, b, row_base, dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact);
         const unsigned long long valid_mask = __ballot(k != 0ull && lane < kprime);
         const int n_valid = __popcll(valid_mask);
         const unsigned long long worst_key = __shfl(k, (n_valid > 0 ? n_valid - 1 : 0), 64);
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
             orr_candidate t;
             const bool kept_all = n_rows <= (int64_t)kprime;
             t.approx_score = (kept_all || n_valid == 0) ? -__builtin_huge_val() : key_score(worst_key);
-            t.dot = 0.0; t.norm_b = 0.0; t.created_ticks = 0;
+            t.dot = approx_eps; t.norm_b = 0.0; t.created_ticks = 0;
             t.row_id = -1; t.order_key = n_rows; t.matches = n_valid; t.flags = ORR_CAND_TRAILER;
             o[kprime] = t;
         }
@@ -648,14 +653,15 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
 }
 
 hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, int32_t kprime,
-                               int64_t n_rows, int64_t row_base, const double *dot, int64_t dot_stride,
-                               const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                               KwView kw, int32_t dot_exact, orr_candidate *out, hipStream_t s)
+                               int64_t n_rows, int64_t row_base, const double *dot, const float *dotf,
+                               int64_t dot_stride, const double *norm_b, const int64_t *created,
+                               const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
+                               orr_candidate *out, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, kprime, n_rows, row_base,
-                       dot, dot_stride, norm_b, created, row_ids, kw, dot_exact, out);
+                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, out);
     return hipGetLastError();
 }
 
@@ -710,9 +716,9 @@ __global__ __launch_bounds__(256) void records_from_sorted_kernel(const unsigned
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K) {
         if ((int64_t)i < n_rows)
-            write_record(out + i, keys[i], vals[i], b, row_base, dot, dot_stride, norm_b, created, row_ids, kw, dot_exact);
+            write_record(out + i, keys[i], vals[i], b, row_base, dot, nullptr, dot_stride, norm_b, created, row_ids, kw, dot_exact);
         else
-            write_record(out + i, 0ull, 0u, b, row_base, dot, dot_stride, norm_b, created, row_ids, kw, dot_exact);
+            write_record(out + i, 0ull, 0u, b, row_base, dot, nullptr, dot_stride, norm_b, created, row_ids, kw, dot_exact);
     } else if (i == K) {
         orr_candidate t;
         const int64_t n_valid = n_rows < (int64_t)K ? n_rows : (int64_t)K;

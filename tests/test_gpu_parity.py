@@ -224,3 +224,50 @@ def test_two_shards_on_one_gpu_equal_one_shard():
     whole.close()
     for p in parts:
         p.close()
+
+
+@pytest.mark.parametrize("B,n,dim", [(9, 700, 64), (40, 5000, 128), (130, 3000, 256), (256, 20000, 768)])
+def test_batched_mfma_candidate_pass_plus_exact_rescore_matches_oracle(B, n, dim):
+    """Batches >= 9 take K2 (f32 MFMA candidate pass) + K6 (exact re-score): the final ranking and
+    scores must still be bit-identical to the oracle."""
+    P = pkg()
+    rng = np.random.default_rng(B * 7 + n)
+    c = random_corpus(rng, n, dim, sorted_created=False)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    some = [r for r in range(n) if c["emb"][r] is not None][:3]
+    for i, r in enumerate(some):
+        qs[i] = c["emb"][r]                                   # exact cosine-1 rows and their duplicates
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    idx.set_profiling(True)
+    rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    stats = idx.kernel_stats()
+    assert "gemm_dot_f32" in stats and "rescore_exact" in stats, stats.keys()
+    check = range(B) if n <= 5000 else range(0, B, 16)
+    for b in check:
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+        assert list(rows[b, :counts[b]]) == list(orow), b
+        assert np.array_equal(scores[b, :counts[b]], osc), b
+    idx.close()
+
+
+def test_gemm_candidate_dots_are_within_the_stated_bound():
+    """K2 alone: |fp32 MFMA dot - reference dot| <= (D+2) 2^-24 sum|q_k e_k| (the bound the certificate uses)."""
+    P = pkg()
+    rng = np.random.default_rng(99)
+    n, dim, B = 300, 128, 16
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    idx = P.RecallIndex(dim=dim)
+    idx.append(emb, NOW - np.arange(n, dtype=np.int64), [b"x"] * n)
+    idx.seal()
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    rec = idx.search_shard(qs, [[]] * B, NOW, 64, n)
+    for b in range(B):
+        for c in rec[b, :64]:
+            r = int(c["row_id"])
+            assert c["flags"] & P.native.ORR_CAND_DOT_EXACT
+            assert c["dot"] == orc.dot(qs[b], emb[r])          # after K6 the record holds the exact dot
+        assert rec[b, 64]["dot"] > 0                            # trailer carries the pass's epsilon
+    idx.close()
