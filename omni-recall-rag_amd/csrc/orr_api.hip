@@ -157,7 +157,7 @@ struct orr_index {
     bool sealed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -422,7 +422,7 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_vlen) (void)hipFree(idx->d_vlen);
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
-    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -724,7 +724,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     const size_t rec_bytes = sizeof(orr_candidate) * rec_count;
     // Batched candidate pass on the matrix cores (K2) + exact re-score (K6) from this batch size
     // up; below it the HBM-bound exact kernel is as fast and needs no second pass.
-    static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 9; }();
+    static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
     const bool use_mfma = use_cos && !a.force_exact && B >= mfma_min_batch && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
     a.used_mfma = use_mfma;
     const bool direct_host = host_records && !use_mfma && rec_bytes <= (256u << 10);
@@ -780,8 +780,16 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (use_cos && use_mfma) {
         ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
         d_dotf = idx->ws_dotf.as<float>();
-        Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
-        HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
+        if (B <= 96) {   // HBM-bound streaming form, 32 queries per launch
+            for (int32_t b0 = 0; b0 < B; b0 += 32) {
+                const int32_t nq = std::min<int32_t>(32, B - b0);
+                Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);
+                HIP_TRY(orr::launch_gemv_mfma(d_q + (size_t)b0 * a.dim, nq, idx->d_emb, n, idx->dim, d_dotf + (size_t)b0 * n, n, s));
+            }
+        } else {
+            Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
+            HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
+        }
         // |fmaf chain - reference sum| <= (D+2) 2^-24 sum|q_k e_k| <= (D+2) 2^-24 |q||e|  (Cauchy-Schwarz)
         approx_eps = 0.7 * 1.01 * (double)(idx->dim + 2) * 5.9604644775390625e-08 + 1e-12;
     } else if (use_cos) {
@@ -890,6 +898,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     }
 
     // ---- per-query constants (exact normA needs the vectors on the host)
+    const bool batched_score = B >= 4 && kprime <= orr::kSelWidth;     // per-row pieces once per batch
     if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
     ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
@@ -898,6 +907,12 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         qc[b].use_cos = use_cos ? 1 : 0;
         qc[b].norm_a = use_cos ? exact_norm(idx->pin_q.as<float>() + (size_t)b * a.dim, a.dim) : 0.0;
         qc[b].n_terms = (int32_t)(qoff[b + 1] - qoff[b]);
+        qc[b].inv_n_terms = qc[b].n_terms > 0 ? 1.0 / (double)qc[b].n_terms : 0.0;
+        qc[b].inv_sqrt_na = 0.0;
+        if (batched_score && use_cos) {
+            if (qc[b].norm_a <= 0.0) qc[b].use_cos = 0;                    // guard :84 -> cosine 0 for every row
+            else qc[b].inv_sqrt_na = 1.0 / std::sqrt(qc[b].norm_a);        // NaN stays NaN
+        }
     }
     HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
     if (n_terms_total > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_kw_done, 0));
@@ -906,9 +921,16 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (kprime <= orr::kSelWidth) {
         const int64_t n_seg = (n + orr::kSelSegRows - 1) / orr::kSelSegRows;
         ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)n_seg * orr::kSelWidth));
+        const double2 *d_rowc = nullptr;
+        if (batched_score) {
+            ORR_TRY(idx->ws_rowc.reserve(sizeof(double2) * (size_t)n));
+            Timed t(idx, "row_consts", 32.0 * (double)n);
+            HIP_TRY(orr::launch_row_consts(idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->ws_rowc.as<double2>(), s));
+            d_rowc = idx->ws_rowc.as<double2>();
+        }
         {
             Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0));
-            HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, kw,
+            HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, d_rowc, kw,
                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B,
                                             idx->ws_sel.as<orr::SelEntry>(), s));
         }

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
             stage_write(lds_b, it * 16 + ld_r, ld_c, rb[it]);
         }
         if (k0 + kGemmBK < D) load_stage(k0 + kGemmBK);             // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);                          // keep the loads ABOVE the MFMA block
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 8; ++g) {                               // 4 k-pairs per group
@@ -124,6 +125,182 @@ hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_
     if (D % kGemmBK != 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)((n_rows + kGemmBN - 1) / kGemmBN), (unsigned)((B + kGemmBM - 1) / kGemmBM));
     hipLaunchKernelGGL(gemm_dot_f32_kernel, grid, dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K2s  up to 32 queries per launch, HBM-bound: the streaming structure of
+// dot_exact_tiled (each wave owns 64 rows, 64x64-float pieces staged through a
+// swizzled wave-private LDS tile, next piece prefetched with nontemporal loads,
+// next piece prefetched with nontemporal loads) with the arithmetic on the matrix
+// cores: per 4 floats of a row, two 32x32x2 MFMAs per 32-row half against the 32
+// queries.  Lane l takes dwords k = 4j,4j+2 (l < 32) or 4j+1,4j+3 (l >= 32) of each
+// 16-byte row piece (ds_read2_b32), which is exactly the A/B operand layout.  The matching 32 x 64 query piece is shared by the workgroup's
+// four waves through a double-buffered LDS tile (one barrier per piece).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemv_mfma_kernel(const float *__restrict__ Q, int32_t B,
+                                                        const float *__restrict__ E, int64_t n_rows, int32_t D,
+                                                        float *__restrict__ S, int64_t s_stride)
+{
+    // 4 x 16 KiB wave-private row tiles + 2 x 8 KiB shared query tiles = 80 KiB: two workgroups per CU
+    __shared__ __attribute__((aligned(16))) float tile_all[4][64 * 64];
+    __shared__ __attribute__((aligned(16))) float qtile[2][32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *tile = tile_all[wave];
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ld_row = lane >> 4, ld_ch = lane & 15;
+    const int64_t n_blocks = (n_rows + 255) >> 8;           // 256 rows per workgroup step
+
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int64_t row0 = (blk << 8) + wave * 64;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        float4 stage[16], qreg[2];
+        auto load_stage = [&](int c0) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + ld_row;
+                const int64_t row = row0 + r;
+                stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < n_rows) {
+                    const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + row * (int64_t)D + c0 + ld_ch * 4));
+                    stage[it] = make_float4(v.x, v.y, v.z, v.w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                   // the workgroup's 32 x 64 query piece: 2 float4 per thread
+                const int id = tid + 256 * u, qi = id >> 4, qj = id & 15;
+                qreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qi < B) qreg[u] = *reinterpret_cast<const float4 *>(Q + (int64_t)qi * D + c0 + qj * 4);
+            }
+        };
+        load_stage(0);
+        int buf = 0;
+        for (int c0 = 0; c0 < D; c0 += 64, buf ^= 1) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + ld_row;
+                *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int id = tid + 256 * u, qi = id >> 4, qj = id & 15;
+                *reinterpret_cast<float4 *>(qtile[buf] + qi * 64 + ((qj ^ (qi & 15)) << 2)) = qreg[u];
+            }
+            if (c0 + 64 < D) load_stage(c0 + 64);           // next pieces in flight during the MFMAs
+            __builtin_amdgcn_sched_barrier(0);              // keep the loads ABOVE the MFMA block
+            __syncthreads();                                // one barrier per piece (query tile is double-buffered)
+            const float *qt = qtile[buf];
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int sw = ((j ^ (fr & 15)) << 2) + fh;  // dwords fh and fh+2 of the 16-byte piece: no select
+                const float a_lo = qt[fr * 64 + sw], a_hi = qt[fr * 64 + sw + 2];
+                const float b0_lo = tile[fr * 64 + sw], b0_hi = tile[fr * 64 + sw + 2];
+                const float b1_lo = tile[(32 + fr) * 64 + sw], b1_hi = tile[(32 + fr) * 64 + sw + 2];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b0_lo, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, b1_lo, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b0_hi, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, b1_hi, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                    // before the next row block reuses qtile[0]
+        // C/D layout: column (E row) = lane & 31, query = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qi = (e & 3) + 8 * (e >> 2) + 4 * fh;
+            if (qi < B) {
+                if (row0 + fr < n_rows) S[(int64_t)qi * s_stride + row0 + fr] = acc0[e];
+                if (row0 + 32 + fr < n_rows) S[(int64_t)qi * s_stride + row0 + 32 + fr] = acc1[e];
+            }
+        }
+    }
+}
+
+// K2s for B <= 16: same structure on v_mfma_f32_16x16x4_f32 (A[i = lane & 15][k = lane >> 4]).
+// A 16-byte piece of a row holds exactly one MFMA's four k values: lane (i, kq) reads the
+// dword kq of it (plain ds_read_b32, no select).  64 rows = 4 column tiles of 16, 16 accumulator VGPRs, half the matrix work of
+// the 32-query form, so a batch of up to 16 queries stays HBM-bound.
+__global__ __launch_bounds__(256, 2) void gemv_mfma16_kernel(const float *__restrict__ Q, int32_t B,
+                                                             const float *__restrict__ E, int64_t n_rows, int32_t D,
+                                                             float *__restrict__ S, int64_t s_stride)
+{
+    __shared__ __attribute__((aligned(16))) float tile_all[4][64 * 64];
+    __shared__ __attribute__((aligned(16))) float qtile[2][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *tile = tile_all[wave];
+    const int fr = lane & 15, kq = lane >> 4;
+    const int ld_row = lane >> 4, ld_ch = lane & 15;
+    const int64_t n_blocks = (n_rows + 255) >> 8;
+    const int qi_ld = tid >> 4, qj_ld = tid & 15;           // the 16 x 64 query piece: one float4 per thread
+
+    for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int64_t row0 = (blk << 8) + wave * 64;
+        f32x4v acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        float4 stage[16], qreg;
+        auto load_stage = [&](int c0) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + ld_row;
+                const int64_t row = row0 + r;
+                stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < n_rows) {
+                    const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + row * (int64_t)D + c0 + ld_ch * 4));
+                    stage[it] = make_float4(v.x, v.y, v.z, v.w);
+                }
+            }
+            qreg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qi_ld < B) qreg = *reinterpret_cast<const float4 *>(Q + (int64_t)qi_ld * D + c0 + qj_ld * 4);
+        };
+        load_stage(0);
+        int buf = 0;
+        for (int c0 = 0; c0 < D; c0 += 64, buf ^= 1) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + ld_row;
+                *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
+            }
+            *reinterpret_cast<float4 *>(qtile[buf] + qi_ld * 64 + ((qj_ld ^ (qi_ld & 15)) << 2)) = qreg;
+            if (c0 + 64 < D) load_stage(c0 + 64);
+            __builtin_amdgcn_sched_barrier(0);              // keep the loads ABOVE the MFMA block
+            __syncthreads();
+            const float *qt = qtile[buf];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int sw = ((j ^ fr) << 2) + kq;        // rows 16t + fr: (row & 15) == fr
+                const float a = qt[fr * 64 + sw];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, tile[(16 * t + fr) * 64 + sw], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // C/D layout of the 16x16 MFMA: column (E row) = lane & 15, query = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qi = kq * 4 + e;
+                const int64_t row = row0 + 16 * t + fr;
+                if (qi < B && row < n_rows) S[(int64_t)qi * s_stride + row] = acc[t][e];
+            }
+    }
+}
+
+hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
+                            int64_t s_stride, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (B > 32 || D % 64 != 0) return hipErrorInvalidValue;
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (B <= 16) {
+        hipLaunchKernelGGL(gemv_mfma16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(gemv_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
     return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ namespace orr {
 
 constexpr int kSelWidth = 64;        // entries a wave keeps while selecting (one per lane)
 constexpr int kSelSegRows = 4096;    // rows one workgroup of fuse_select scans
-constexpr int kMaxExactQ = 4;        // queries one launch of the exact dot kernel carries
+constexpr int kMaxExactQ = 8;        // queries one launch of the exact dot kernel carries
 constexpr int kMaxScanTerms = 64;    // query terms one launch of the keyword scan carries
 
 // One selection entry: `key` orders scores (see score_key in the .hip), `pos` is the
@@ -77,16 +77,23 @@ hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *count
 // Per-query constants of the fused score.
 struct QueryConst {
     double norm_a;        // exact sum_i (double)fl32(q_i^2); unused when use_cos == 0
+    double inv_sqrt_na;   // 1/sqrt(norm_a) for the batched selection score
+    double inv_n_terms;   // 1/queryTerms.Length, 0 without terms
     int32_t n_terms;      // queryTerms.Length (RecallSearchService.cs:112)
-    int32_t use_cos;      // query dim == index dim and dim > 0
+    int32_t use_cos;      // query dim == index dim, dim > 0 (and norm_a > 0 in the batched form)
 };
+
+// Per-row selection constants for a batch: out[r] = {1/sqrt(normB) or 0, recency * 0.1}.
+hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64_t now_ticks, int64_t n_rows,
+                             double2 *out, hipStream_t s);
 
 // K4+K5a: fused score per (query,row) and per-workgroup top-64.
 //   score = (cos*0.7) + (kw*0.2) + (rec*0.1)  in fp64, left to right (…cs:66)
 // out_sel: [B][n_seg][kSelWidth] entries, best first.  n_seg = ceil(n_rows / kSelSegRows).
 // dot (fp64, exact pass) or dotf (fp32, K2 candidate pass): exactly one is non-null when cosine applies.
+// row_consts != nullptr selects the batched (reciprocal-multiply) form of the score.
 hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
-                              const int64_t *created, KwView kw,
+                              const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               SelEntry *out_sel, hipStream_t s);
 
@@ -104,6 +111,9 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
 // order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
 hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                                int64_t s_stride, hipStream_t s);
+// K2s: the same for B <= 32 queries, streaming (HBM-bound) structure.
+hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
+                            int64_t s_stride, hipStream_t s);
 // K6: recomputes records[b][c].dot in the reference's exact arithmetic for every valid record
 // (row = order_key - row_base) and sets ORR_CAND_DOT_EXACT.
 hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32_t B, int32_t kprime, int64_t row_base,

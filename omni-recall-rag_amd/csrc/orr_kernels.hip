@@ -56,6 +56,44 @@ __device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t
     return (cosv * 0.7) + (kw * 0.2) + (rec * 0.1);                          // :66
 }
 
+// Selection-only form of the fused score for batches: per-row pieces (recency * 0.1 and
+// 1/sqrt(normB)) are computed once per batch (row_consts_kernel), per-query 1/sqrt(normA) on
+// the host.  It differs from fused_score by a few ulp (reciprocal-multiply instead of divide),
+// far inside the certificate's slack; the survivors are always re-scored exactly on the host.
+__device__ __forceinline__ double fused_score_fast(double dot, double inv_sqrt_nb, double rec01, uint32_t matches,
+                                                   const QueryConst &qc)
+{
+    double cosv = 0.0;
+    if (qc.use_cos) cosv = (inv_sqrt_nb == 0.0) ? 0.0 : dot * (qc.inv_sqrt_na * inv_sqrt_nb);   // normB <= 0 -> 0 (:84)
+    const double kw = (double)matches * qc.inv_n_terms;
+    return (cosv * 0.7) + (kw * 0.2) + rec01;
+}
+
+__global__ __launch_bounds__(256) void row_consts_kernel(const double *__restrict__ norm_b,
+                                                         const int64_t *__restrict__ created, int64_t now_ticks,
+                                                         int64_t n_rows, double2 *__restrict__ out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const double nb = norm_b[r];
+        const double total_days = (double)(now_ticks - created[r]) / 864000000000.0;
+        const double age_days = total_days > 0.0 ? total_days : 0.0;
+        double2 o;
+        o.x = nb <= 0.0 ? 0.0 : 1.0 / sqrt(nb);          // NaN stays NaN
+        o.y = exp(-age_days / 30.0) * 0.1;
+        out[r] = o;
+    }
+}
+
+hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64_t now_ticks, int64_t n_rows,
+                             double2 *out, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(row_consts_kernel, dim3((unsigned)blocks), dim3(256), 0, s, norm_b, created, now_ticks, n_rows, out);
+    return hipGetLastError();
+}
+
 // matches of RecallSearchService.cs:111 for (query b, row): how many of the query's
 // distinct terms have their bit set in the per-term row bitmaps (see expand_hits_kernel).
 __device__ __forceinline__ uint32_t kw_matches(const KwView &kw, int b, uint32_t row)
@@ -221,7 +259,11 @@ hipError_t launch_dot_exact(const float *E, int64_t n_rows, int32_t D, const flo
         case 1: ORR_LAUNCH_DOT(1, false); break;
         case 2: ORR_LAUNCH_DOT(2, false); break;
         case 3: ORR_LAUNCH_DOT(3, false); break;
-        default: ORR_LAUNCH_DOT(4, false); break;
+        case 4: ORR_LAUNCH_DOT(4, false); break;
+        case 5: ORR_LAUNCH_DOT(5, false); break;
+        case 6: ORR_LAUNCH_DOT(6, false); break;
+        case 7: ORR_LAUNCH_DOT(7, false); break;
+        default: ORR_LAUNCH_DOT(8, false); break;
         }
     }
 #undef ORR_LAUNCH_DOT
@@ -366,10 +408,10 @@ __global__ __launch_bounds__(256) void vocab_hits_kernel(const uint16_t *__restr
                                                          unsigned long long *__restrict__ counter,
                                                          KwHit *__restrict__ hits, uint32_t max_hits)
 {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_tokens) return;
-    for (int t = 0; t < n_terms; ++t) {
-        if (vmatch[(int64_t)t * n_tokens + v] == 0) continue;
+    const int64_t total = n_tokens * (int64_t)n_terms;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        if (vmatch[id] == 0) continue;                       // vmatch is [term][token]
+        const int64_t t = id / n_tokens, v = id - t * n_tokens;
         const uint64_t p0 = post_off[v], p1 = post_off[v + 1];
         const uint32_t chunks = (uint32_t)((p1 - p0 + kPostChunk - 1) / kPostChunk);
         const unsigned long long old = atomicAdd(counter, (1ull << 32) | chunks);
@@ -415,7 +457,8 @@ hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n
                              unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s)
 {
     if (n_tokens <= 0 || n_terms <= 0) return hipSuccess;
-    const int64_t blocks = (n_tokens + 255) / 256;
+    int64_t blocks = (n_tokens * (int64_t)n_terms + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(vocab_hits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vmatch, n_tokens, n_terms, post_off,
                        counter, hits, max_hits);
     return hipGetLastError();
@@ -483,10 +526,12 @@ __device__ __forceinline__ void wave_merge_sorted(unsigned long long &k, uint32_
 // (lane = row, coalesced 8-byte reads), skips batches that cannot enter its
 // list, and the four lists are merged through LDS at the end.
 // ---------------------------------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restrict__ dot,
                                                            const float *__restrict__ dotf, int64_t dot_stride,
                                                            const double *__restrict__ norm_b,
-                                                           const int64_t *__restrict__ created, KwView kw,
+                                                           const int64_t *__restrict__ created,
+                                                           const double2 *__restrict__ row_consts, KwView kw,
                                                            const QueryConst *__restrict__ qcs,
                                                            int64_t now_ticks, int64_t n_rows,
                                                            SelEntry *__restrict__ out_sel)
@@ -494,9 +539,10 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;                        // queries vary fastest: neighbouring workgroups share a segment
+    const int seg = blockIdx.y;
     const QueryConst qc = qcs[b];
-    const int64_t seg0 = (int64_t)blockIdx.x * kSelSegRows;
+    const int64_t seg0 = (int64_t)seg * kSelSegRows;
     const int64_t seg1 = (seg0 + kSelSegRows < n_rows) ? seg0 + kSelSegRows : n_rows;
 
     // each of the 16 waves scores kSelSegRows/16 = 256 rows: 4 batches of 64 whose loads are
@@ -516,7 +562,12 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
                              : dotf  ? (double)dotf[(int64_t)b * dot_stride + r]     // K2 candidate pass
                                      : dot[(int64_t)b * dot_stride + r];             // K1e exact
             const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)r) : 0u;
-            nk[u] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
+            if (FAST) {
+                const double2 rc = row_consts[r];
+                nk[u] = score_key(fused_score_fast(d, rc.x, rc.y, m, qc));
+            } else {
+                nk[u] = score_key(fused_score(d, norm_b[r], created[r], m, qc, now_ticks));
+            }
             np[u] = (uint32_t)r;
         }
     }
@@ -547,19 +598,24 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
     if (wave == 0) {
         SelEntry e;
         e.key = k; e.pos = p; e.pad = 0;
-        out_sel[((int64_t)b * gridDim.x + blockIdx.x) * kSelWidth + lane] = e;
+        out_sel[((int64_t)b * gridDim.y + seg) * kSelWidth + lane] = e;
     }
 }
 
 hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
-                              const int64_t *created, KwView kw,
+                              const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               SelEntry *out_sel, hipStream_t s)
 {
     if (n_rows <= 0 || B <= 0) return hipSuccess;
     const int64_t n_seg = (n_rows + kSelSegRows - 1) / kSelSegRows;
-    hipLaunchKernelGGL(fuse_select_kernel, dim3((unsigned)n_seg, (unsigned)B), dim3(1024), 0, s, dot, dotf, dot_stride,
-                       norm_b, created, kw, qc, now_ticks, n_rows, out_sel);
+    if (n_seg > 65535) return hipErrorInvalidValue;
+    if (row_consts)
+        hipLaunchKernelGGL(fuse_select_kernel<true>, dim3((unsigned)B, (unsigned)n_seg), dim3(1024), 0, s, dot, dotf, dot_stride,
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, out_sel);
+    else
+        hipLaunchKernelGGL(fuse_select_kernel<false>, dim3((unsigned)B, (unsigned)n_seg), dim3(1024), 0, s, dot, dotf, dot_stride,
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, out_sel);
     return hipGetLastError();
 }
 
