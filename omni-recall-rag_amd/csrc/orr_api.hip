@@ -157,7 +157,7 @@ struct orr_index {
     bool sealed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -422,7 +422,7 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_vlen) (void)hipFree(idx->d_vlen);
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
-    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -928,17 +928,36 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             HIP_TRY(orr::launch_row_consts(idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->ws_rowc.as<double2>(), s));
             d_rowc = idx->ws_rowc.as<double2>();
         }
+        // Large batches: scan a prefix first, take its k'-th best key per query as a floor, and let
+        // the rest of the corpus skip every 64-row batch that cannot beat it.
+        const int32_t n_seg32 = (int32_t)n_seg;
+        const int32_t sample_seg = (B >= 8 && n_seg32 >= 48) ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg32 / 16)) : 0;
+        unsigned long long *d_tau = nullptr;
+        if (sample_seg > 0) {
+            ORR_TRY(idx->ws_tau.reserve(sizeof(unsigned long long) * (size_t)B));
+            d_tau = idx->ws_tau.as<unsigned long long>();
+            {
+                Timed t(idx, "fuse_select", (double)B * (double)sample_seg * orr::kSelSegRows * 28.0);
+                HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, d_rowc, kw,
+                                                idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B, 0, sample_seg, nullptr,
+                                                idx->ws_sel.as<orr::SelEntry>(), s));
+            }
+            {
+                Timed t(idx, "select_floor", 0.0);
+                HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), n_seg32, sample_seg, B, kprime, d_tau, s));
+            }
+        }
         {
             Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0));
             HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, d_rowc, kw,
-                                            idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B,
-                                            idx->ws_sel.as<orr::SelEntry>(), s));
+                                            idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B, sample_seg, n_seg32 - sample_seg,
+                                            d_tau, idx->ws_sel.as<orr::SelEntry>(), s));
         }
         {
             Timed t(idx, "select_final", (double)B * (double)n_seg * orr::kSelWidth * sizeof(orr::SelEntry));
             HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), (int32_t)n_seg, B, kprime, n, idx->row_base,
                                              d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                             use_mfma ? 0 : 1, approx_eps, d_cand, s));
+                                             use_mfma ? 0 : 1, approx_eps, nullptr, d_cand, s));
         }
         if (use_mfma) {   // K6: the survivors' dots again, now in the reference's own arithmetic
             Timed t(idx, "rescore_exact", (double)B * kprime * 4.0 * idx->dim);

@@ -92,20 +92,24 @@ hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64
 // out_sel: [B][n_seg][kSelWidth] entries, best first.  n_seg = ceil(n_rows / kSelSegRows).
 // dot (fp64, exact pass) or dotf (fp32, K2 candidate pass): exactly one is non-null when cosine applies.
 // row_consts != nullptr selects the batched (reciprocal-multiply) form of the score.
+// Scans segments [seg_first, seg_first+seg_count); tau != nullptr: per-query key a row must
+// exceed to be considered (the k'-th best key of an already scanned prefix).
 hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
+                              int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
                               SelEntry *out_sel, hipStream_t s);
 
 // K5b: merges the per-workgroup lists of each query and writes kprime candidate
 // records plus the trailer ([B][kprime+1], see orr_candidate).
+// tau_out != nullptr: write only the k'-th best key per query (sampling pass), no records.
 // approx_eps goes into the trailer's `dot` field: the bound on |selection score - exact score|
 // of the pass that produced the records (0 for the exact pass).
 hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, int32_t kprime,
                                int64_t n_rows, int64_t row_base, const double *dot, const float *dotf,
                                int64_t dot_stride, const double *norm_b, const int64_t *created,
                                const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
-                               orr_candidate *out, hipStream_t s);
+                               unsigned long long *tau_out, orr_candidate *out, hipStream_t s);
 
 // K2: S[b][r] ~= sum_k Q[b][k] * E[r][k] on the matrix cores (f32-input MFMA, fmaf chain in k
 // order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
@@ -118,6 +122,11 @@ hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n
 // (row = order_key - row_base) and sets ORR_CAND_DOT_EXACT.
 hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32_t B, int32_t kprime, int64_t row_base,
                                 orr_candidate *recs, hipStream_t s);
+
+// Sampling pass of the batched selection: tau_out[b] = k'-th best key among the first sample_seg
+// lists of query b (0 if there are fewer).
+hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
+                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s);
 
 // Generic path for large k: keys[r] = score key of (query b,row r), vals[r] = r.
 hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,

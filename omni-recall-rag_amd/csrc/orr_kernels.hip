@@ -533,15 +533,20 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
                                                            const int64_t *__restrict__ created,
                                                            const double2 *__restrict__ row_consts, KwView kw,
                                                            const QueryConst *__restrict__ qcs,
-                                                           int64_t now_ticks, int64_t n_rows,
+                                                           int64_t now_ticks, int64_t n_rows, int32_t seg_first,
+                                                           int32_t n_seg_total,
+                                                           const unsigned long long *__restrict__ tau,
                                                            SelEntry *__restrict__ out_sel)
 {
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.x;                        // queries vary fastest: neighbouring workgroups share a segment
-    const int seg = blockIdx.y;
+    const int seg = seg_first + blockIdx.y;
     const QueryConst qc = qcs[b];
+    // Rows after the sampled prefix only matter if they beat the k'-th best key of the prefix
+    // (equal keys lose the position tie-break to the prefix rows): most batches are skipped.
+    const unsigned long long floor_key = tau ? tau[b] : 0ull;
     const int64_t seg0 = (int64_t)seg * kSelSegRows;
     const int64_t seg1 = (seg0 + kSelSegRows < n_rows) ? seg0 + kSelSegRows : n_rows;
 
@@ -574,14 +579,15 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (seg0 + (int64_t)(wave * U + u) * 64 >= seg1) break;
-        if (u > 0) {
-            const unsigned long long tk = __shfl(k, 63, 64);
-            const uint32_t tp = __shfl(p, 63, 64);
-            if (!__any(better(nk[u], np[u], tk, tp))) continue;
+        if (floor_key) {
+            if (!__any(nk[u] > floor_key)) continue;
+            if (nk[u] <= floor_key) { nk[u] = 0ull; np[u] = 0xFFFFFFFFu; }
         }
+        const unsigned long long tk = __shfl(k, 63, 64);
+        const uint32_t tp = __shfl(p, 63, 64);
+        if (!__any(better(nk[u], np[u], tk, tp))) continue;
         wave_sort(nk[u], np[u], lane);
-        if (u == 0) { k = nk[0]; p = np[0]; }
-        else wave_merge_sorted(k, p, nk[u], np[u], lane);
+        wave_merge_sorted(k, p, nk[u], np[u], lane);
     }
     lists[wave][lane].key = k;
     lists[wave][lane].pos = p;
@@ -598,24 +604,25 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
     if (wave == 0) {
         SelEntry e;
         e.key = k; e.pos = p; e.pad = 0;
-        out_sel[((int64_t)b * gridDim.y + seg) * kSelWidth + lane] = e;
+        out_sel[((int64_t)b * n_seg_total + seg) * kSelWidth + lane] = e;
     }
 }
 
 hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
+                              int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
                               SelEntry *out_sel, hipStream_t s)
 {
-    if (n_rows <= 0 || B <= 0) return hipSuccess;
+    if (n_rows <= 0 || B <= 0 || seg_count <= 0) return hipSuccess;
     const int64_t n_seg = (n_rows + kSelSegRows - 1) / kSelSegRows;
     if (n_seg > 65535) return hipErrorInvalidValue;
     if (row_consts)
-        hipLaunchKernelGGL(fuse_select_kernel<true>, dim3((unsigned)B, (unsigned)n_seg), dim3(1024), 0, s, dot, dotf, dot_stride,
-                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, out_sel);
+        hipLaunchKernelGGL(fuse_select_kernel<true>, dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel);
     else
-        hipLaunchKernelGGL(fuse_select_kernel<false>, dim3((unsigned)B, (unsigned)n_seg), dim3(1024), 0, s, dot, dotf, dot_stride,
-                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, out_sel);
+        hipLaunchKernelGGL(fuse_select_kernel<false>, dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel);
     return hipGetLastError();
 }
 
@@ -646,20 +653,21 @@ __device__ __forceinline__ void write_record(orr_candidate *o, unsigned long lon
 // 4-level tree through LDS; wave 0 writes kprime records and the trailer.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__restrict__ sel, int32_t n_seg,
-                                                            int32_t kprime, int64_t n_rows, int64_t row_base,
+                                                            int32_t seg_stride, int32_t kprime, int64_t n_rows, int64_t row_base,
                                                             const double *__restrict__ dot,
                                                             const float *__restrict__ dotf, int64_t dot_stride,
                                                             const double *__restrict__ norm_b,
                                                             const int64_t *__restrict__ created,
                                                             const int64_t *__restrict__ row_ids, KwView kw,
                                                             int32_t dot_exact, double approx_eps,
+                                                            unsigned long long *__restrict__ tau_out,
                                                             orr_candidate *__restrict__ out)
 {
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
-    const SelEntry *mine = sel + (int64_t)b * n_seg * kSelWidth;
+    const SelEntry *mine = sel + (int64_t)b * seg_stride * kSelWidth;
 
     unsigned long long k = 0ull;
     uint32_t p = 0xFFFFFFFFu;
@@ -690,6 +698,11 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
         }
         __syncthreads();
     }
+    if (wave == 0 && tau_out) {      // sampling pass: only the k'-th best key of these lists is wanted
+        const unsigned long long kth = __shfl(k, kprime - 1, 64);
+        if (lane == 0) tau_out[b] = kth;          // 0 (empty slot) if fewer than k' rows: no filtering
+        return;
+    }
     if (wave == 0) {
         orr_candidate *o = out + (int64_t)b * (kprime + 1);
         if (lane < kprime)
@@ -712,12 +725,24 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
                                int64_t n_rows, int64_t row_base, const double *dot, const float *dotf,
                                int64_t dot_stride, const double *norm_b, const int64_t *created,
                                const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
-                               orr_candidate *out, hipStream_t s)
+                               unsigned long long *tau_out, orr_candidate *out, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, kprime, n_rows, row_base,
-                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, out);
+    hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, n_seg, kprime, n_rows, row_base,
+                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
+                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s)
+{
+    if (B <= 0 || sample_seg <= 0) return hipSuccess;
+    if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
+    const KwView nokw{nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, sample_seg, n_seg_total, kprime,
+                       (int64_t)0, (int64_t)0, nullptr, nullptr, (int64_t)0, nullptr, nullptr, nullptr, nokw, 0, 0.0,
+                       tau_out, nullptr);
     return hipGetLastError();
 }
 
