@@ -8,6 +8,8 @@
 // result against the cut-off (orr_api.hip).
 #include "orr_kernels.h"
 
+#include <cstdlib>
+
 namespace orr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,14 +55,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
     auto load_stage = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+            // rows past the end are clamped, not branched around (a branch per load makes hipcc wait
+            // vmcnt(0) between loads); what they contribute lands in outputs that are never stored
             const int r = it * 16 + ld_r;
-            ra[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + r < B) ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)(b0 + r) * D + k0 + ld_c * 4);
-            if (n0 + r < n_rows) {
-                const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + (n0 + r) * (int64_t)D + k0 + ld_c * 4));
-                rb[it] = make_float4(v.x, v.y, v.z, v.w);
-            }
+            const int qr = (b0 + r < B) ? b0 + r : B - 1;
+            const int64_t er = (n0 + r < n_rows) ? n0 + r : n_rows - 1;
+            ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)qr * D + k0 + ld_c * 4);
+            const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + er * (int64_t)D + k0 + ld_c * 4));
+            rb[it] = make_float4(v.x, v.y, v.z, v.w);
         }
     };
 
@@ -118,13 +120,120 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
         }
 }
 
+// K2 v2: same tile and LDS image, but the image is DOUBLE-BUFFERED (139 KiB: one workgroup
+// per CU, one wave per SIMD) and the staging of K-step t+1 (ds_write of registers loaded one
+// step earlier) and the global loads of K-step t+2 are issued from INSIDE the MFMA block of
+// K-step t, with one barrier per K-step.  Measured (B=256, 1M rows): 16.0 ms against 14.2 ms
+// for v1 once v1's per-load branches were removed -- with one wave per SIMD the LDS-read
+// latency at the head of every MFMA group is exposed, v1's second wave covers it.  Kept as
+// ORR_GEMM_VARIANT=2 for comparison; v1 is the default.
+__global__ __launch_bounds__(256, 1) void gemm_dot_f32_db_kernel(const float *__restrict__ Q, int32_t B,
+                                                                 const float *__restrict__ E, int64_t n_rows, int32_t D,
+                                                                 float *__restrict__ S, int64_t s_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][A 128x68 | B 128x68]
+    constexpr int kTile = kGemmBM * kGemmLd;                        // floats per operand tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t n0 = (int64_t)blockIdx.x * kGemmBN;
+    const int b0 = blockIdx.y * kGemmBM;
+    const int ld_r = tid >> 4, ld_c = tid & 15;
+    float4 ra[8], rb[8];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            // rows past the end are clamped, not branched around (a branch per load makes hipcc wait
+            // vmcnt(0) between loads); what they contribute lands in outputs that are never stored
+            const int r = it * 16 + ld_r;
+            const int qr = (b0 + r < B) ? b0 + r : B - 1;
+            const int64_t er = (n0 + r < n_rows) ? n0 + r : n_rows - 1;
+            ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)qr * D + k0 + ld_c * 4);
+            const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + er * (int64_t)D + k0 + ld_c * 4));
+            rb[it] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto store_stage = [&](float *buf) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            stage_write(buf, it * 16 + ld_r, ld_c, ra[it]);
+            stage_write(buf + kTile, it * 16 + ld_r, ld_c, rb[it]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_off = (wm * 64 + fr) * kGemmLd + fh * 32;
+    const int b_off = kTile + (wn * 64 + fr) * kGemmLd + fh * 32;
+
+    const int n_steps = D / kGemmBK;
+    load_stage(0);
+    store_stage(lds);
+    if (n_steps > 1) load_stage(kGemmBK);
+    for (int t = 0; t < n_steps; ++t) {
+        const float *cur = lds + (t & 1) * 2 * kTile;
+        float *nxt = lds + ((t + 1) & 1) * 2 * kTile;
+        __syncthreads();          // image t complete; everyone is done reading image t-1 (= nxt)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(cur + a_off + 4 * g);
+            const float4 a1 = *reinterpret_cast<const float4 *>(cur + a_off + 32 * kGemmLd + 4 * g);
+            const float4 c0 = *reinterpret_cast<const float4 *>(cur + b_off + 4 * g);
+            const float4 c1 = *reinterpret_cast<const float4 *>(cur + b_off + 32 * kGemmLd + 4 * g);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {c0.x, c0.y, c0.z, c0.w}, bv1[4] = {c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+            }
+            if (g == 1) {         // behind 32 MFMAs: stage image t+1 from the registers loaded a step ago
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < n_steps) store_stage(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 3) {         // and put K-step t+2 in flight
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < n_steps) load_stage((t + 2) * kGemmBK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+            }
+        }
+}
+
 hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                                int64_t s_stride, hipStream_t s)
 {
     if (B <= 0 || n_rows <= 0) return hipSuccess;
     if (D % kGemmBK != 0) return hipErrorInvalidValue;
     dim3 grid((unsigned)((n_rows + kGemmBN - 1) / kGemmBN), (unsigned)((B + kGemmBM - 1) / kGemmBM));
-    hipLaunchKernelGGL(gemm_dot_f32_kernel, grid, dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
+    static const int variant = [] { const char *e = getenv("ORR_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 1) {
+        hipLaunchKernelGGL(gemm_dot_f32_kernel, grid, dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
+        return hipGetLastError();
+    }
+    constexpr size_t lds_bytes = sizeof(float) * 4 * kGemmBM * kGemmLd;          // 139,264 B
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_f32_db_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(gemm_dot_f32_db_kernel, grid, dim3(256), lds_bytes, s, Q, B, E, n_rows, D, S, s_stride);
     return hipGetLastError();
 }
 
