@@ -777,6 +777,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     double *d_dot = nullptr;
     float *d_dotf = nullptr;
     double approx_eps = 0.0;
+    bool bf16_split = false;
     if (use_cos && use_mfma) {
         ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
         d_dotf = idx->ws_dotf.as<float>();
@@ -787,11 +788,22 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 HIP_TRY(orr::launch_gemv_mfma(d_q + (size_t)b0 * a.dim, nq, idx->d_emb, n, idx->dim, d_dotf + (size_t)b0 * n, n, s));
             }
         } else {
-            Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
-            HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
+            static const bool f32_gemm = [] { const char *e = getenv("ORR_GEMM_KIND"); return e && strcmp(e, "f32") == 0; }();
+            if (f32_gemm) {
+                Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
+                HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
+            } else {
+                Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)n * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
+                HIP_TRY(orr::launch_gemm_dot_bf16x3(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
+                bf16_split = true;
+            }
         }
-        // |fmaf chain - reference sum| <= (D+2) 2^-24 sum|q_k e_k| <= (D+2) 2^-24 |q||e|  (Cauchy-Schwarz)
-        approx_eps = 0.7 * 1.01 * (double)(idx->dim + 2) * 5.9604644775390625e-08 + 1e-12;
+        // f32 MFMA: |fmaf chain - reference sum| <= (D+2) 2^-24 sum|q_k e_k|; split bf16: see orr_gemm.hip.
+        // sum|q_k e_k| <= |q||e| (Cauchy-Schwarz) turns either into a bound on the cosine.
+        const double u24 = 5.9604644775390625e-08;
+        const double eps_cos = bf16_split ? 3.1 * 3.814697265625e-06 + (6.0 * idx->dim / 16.0 + 65.0) * u24
+                                          : (double)(idx->dim + 2) * u24;
+        approx_eps = 0.7 * 1.01 * eps_cos + 1e-12;
     } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
         d_dot = idx->ws_dot.as<double>();

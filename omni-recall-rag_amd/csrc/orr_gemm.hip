@@ -120,6 +120,141 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
         }
 }
 
+// ---------------------------------------------------------------------------
+// K2b  split-bf16 candidate pass: every fp32 operand x is split on the fly into
+// hi = bf16(x) and lo = bf16(x - hi); the dot is accumulated from the three
+// products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA
+// rate per instruction, 3 instructions -> 5.3x), reading the fp32 master copy
+// once.  bf16 x bf16 products are exact in the fp32 accumulator, so
+//   |S - sum q_k e_k| <= [ 3.1 * 2^-18  (dropped lo*lo and second-order residuals)
+//                         + (6 D / 16 + 64) * 2^-24 (fp32 accumulation, doubled) ] * sum|q_k e_k|
+// which is the epsilon the certificate is given (orr_api.hip).
+//
+// Same 128 x 128 x 64 tiling as K2 (4 waves x 2x2 MFMA tiles).  LDS: hi and lo
+// images of both operand tiles, [128 rows][64 k] bf16 with a 144-byte row stride
+// (conflict-free ds_read_b128 of the 8 consecutive k a lane's A/B fragment holds),
+// 72 KiB per workgroup, two workgroups per CU.  Workgroups that score the same
+// rows against different query tiles are placed on one XCD back to back, so the
+// second read of the row tile comes from that XCD's L2 (default cache policy here).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kBfLd = 72;        // bf16 elements per LDS row (64 + 8 pad)
+
+__device__ __forceinline__ void split_write(__bf16 *hi_img, __bf16 *lo_img, int r, int c4, const float4 &v)
+{
+    const __bf16 h0 = (__bf16)v.x, h1 = (__bf16)v.y, h2 = (__bf16)v.z, h3 = (__bf16)v.w;
+    bf16x4 h, l;
+    h[0] = h0; h[1] = h1; h[2] = h2; h[3] = h3;
+    l[0] = (__bf16)(v.x - (float)h0);
+    l[1] = (__bf16)(v.y - (float)h1);
+    l[2] = (__bf16)(v.z - (float)h2);
+    l[3] = (__bf16)(v.w - (float)h3);
+    *reinterpret_cast<bf16x4 *>(hi_img + r * kBfLd + 4 * c4) = h;
+    *reinterpret_cast<bf16x4 *>(lo_img + r * kBfLd + 4 * c4) = l;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_dot_bf16x3_kernel(const float *__restrict__ Q, int32_t B,
+                                                                 const float *__restrict__ E, int64_t n_rows, int32_t D,
+                                                                 float *__restrict__ S, int64_t s_stride,
+                                                                 int32_t n_ntiles, int32_t n_mtiles)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 img[4][kGemmBM * kBfLd];     // A_hi, A_lo, B_hi, B_lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware order: ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int mt = slot % n_mtiles, nt = (slot / n_mtiles) * 8 + xcd;
+    if (nt >= n_ntiles) return;
+    const int64_t n0 = (int64_t)nt * kGemmBN;
+    const int b0 = mt * kGemmBM;
+
+    const int ld_r = tid >> 4, ld_c = tid & 15;
+    float4 ra[8], rb[8];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {     // clamped, never branched around (see K2)
+            const int r = it * 16 + ld_r;
+            const int qr = (b0 + r < B) ? b0 + r : B - 1;
+            const int64_t er = (n0 + r < n_rows) ? n0 + r : n_rows - 1;
+            ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)qr * D + k0 + ld_c * 4);
+            rb[it] = *reinterpret_cast<const float4 *>(E + er * (int64_t)D + k0 + ld_c * 4);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_off = (wm * 64 + fr) * kBfLd + fh * 8;
+    const int b_off = (wn * 64 + fr) * kBfLd + fh * 8;
+
+    load_stage(0);
+    for (int k0 = 0; k0 < D; k0 += kGemmBK) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            split_write(img[0], img[1], it * 16 + ld_r, ld_c, ra[it]);
+            split_write(img[2], img[3], it * 16 + ld_r, ld_c, rb[it]);
+        }
+        if (k0 + kGemmBK < D) load_stage(k0 + kGemmBK);
+        __builtin_amdgcn_sched_barrier(0);                          // loads stay above the MFMA block
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                            // 16 k per MFMA
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8 *>(img[0] + a_off + i * 32 * kBfLd + ks * 16);
+                al[i] = *reinterpret_cast<const bf16x8 *>(img[1] + a_off + i * 32 * kBfLd + ks * 16);
+                bh[i] = *reinterpret_cast<const bf16x8 *>(img[2] + b_off + i * 32 * kBfLd + ks * 16);
+                bl[i] = *reinterpret_cast<const bf16x8 *>(img[3] + b_off + i * 32 * kBfLd + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t col = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+            }
+        }
+}
+
+hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
+                                  int64_t s_stride, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (D % kGemmBK != 0) return hipErrorInvalidValue;
+    const int64_t n_ntiles = (n_rows + kGemmBN - 1) / kGemmBN;
+    const int32_t n_mtiles = (B + kGemmBM - 1) / kGemmBM;
+    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_dot_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride,
+                       (int32_t)n_ntiles, n_mtiles);
+    return hipGetLastError();
+}
+
 // K2 v2: same tile and LDS image, but the image is DOUBLE-BUFFERED (139 KiB: one workgroup
 // per CU, one wave per SIMD) and the staging of K-step t+1 (ds_write of registers loaded one
 // step earlier) and the global loads of K-step t+2 are issued from INSIDE the MFMA block of

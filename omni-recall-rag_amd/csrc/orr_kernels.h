@@ -115,6 +115,10 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
 // order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
 hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                                int64_t s_stride, hipStream_t s);
+// K2b: the same S from three bf16 MFMA products of on-the-fly hi/lo splits (see orr_gemm.hip for
+// the error bound); D % 64 == 0.
+hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
+                                  int64_t s_stride, hipStream_t s);
 // K2s: the same for B <= 32 queries, streaming (HBM-bound) structure.
 hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                             int64_t s_stride, hipStream_t s);

@@ -244,7 +244,7 @@ def test_batched_mfma_candidate_pass_plus_exact_rescore_matches_oracle(B, n, dim
     idx.set_profiling(True)
     rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=n)
     stats = idx.kernel_stats()
-    assert ("gemm_dot_f32" if B > 96 else "gemv_mfma") in stats and "rescore_exact" in stats, stats.keys()
+    assert ("gemm_dot_bf16x3" if B > 96 else "gemv_mfma") in stats and "rescore_exact" in stats, stats.keys()
     check = range(B) if n <= 5000 else range(0, B, 16)
     for b in check:
         orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
