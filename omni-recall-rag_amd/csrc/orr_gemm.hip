@@ -8,6 +8,7 @@
 // result against the cut-off (orr_api.hip).
 #include "orr_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace orr {
@@ -130,12 +131,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
 //                         + (6 D / 16 + 64) * 2^-24 (fp32 accumulation, doubled) ] * sum|q_k e_k|
 // which is the epsilon the certificate is given (orr_api.hip).
 //
-// Same 128 x 128 x 64 tiling as K2 (4 waves x 2x2 MFMA tiles).  LDS: hi and lo
-// images of both operand tiles, [128 rows][64 k] bf16 with a 144-byte row stride
-// (conflict-free ds_read_b128 of the 8 consecutive k a lane's A/B fragment holds),
-// 72 KiB per workgroup, two workgroups per CU.  Workgroups that score the same
-// rows against different query tiles are placed on one XCD back to back, so the
-// second read of the row tile comes from that XCD's L2 (default cache policy here).
+// LDS: hi and lo images of both operand tiles, [rows][64 k] bf16 with a 144-byte row
+// stride (conflict-free ds_read_b128 of the 8 consecutive k a lane's A/B fragment
+// holds).  Workgroups that score the same rows against different query tiles (B > 256)
+// are placed on one XCD back to back, so later reads of the row tile come from that
+// XCD's L2 (default cache policy here).
 // ---------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -154,12 +154,34 @@ __device__ __forceinline__ void split_write(__bf16 *hi_img, __bf16 *lo_img, int 
     *reinterpret_cast<bf16x4 *>(lo_img + r * kBfLd + 4 * c4) = l;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_dot_bf16x3_kernel(const float *__restrict__ Q, int32_t B,
-                                                                 const float *__restrict__ E, int64_t n_rows, int32_t D,
-                                                                 float *__restrict__ S, int64_t s_stride,
+// Queries are split once per batch (split_queries_kernel); the row tile is split by the
+// workgroup that stages it.  Tile: 256 queries x 128 rows x 64 k, 8 waves as 4 x 2, each a
+// 64 x 64 sub-tile, so a row piece is converted once per 256 queries.
+__global__ __launch_bounds__(256) void split_queries_kernel(const float *__restrict__ Q, int64_t n,
+                                                            __bf16 *__restrict__ q_hi, __bf16 *__restrict__ q_lo)
+{
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(Q + i);
+        const __bf16 h0 = (__bf16)v.x, h1 = (__bf16)v.y, h2 = (__bf16)v.z, h3 = (__bf16)v.w;
+        bf16x4 h, l;
+        h[0] = h0; h[1] = h1; h[2] = h2; h[3] = h3;
+        l[0] = (__bf16)(v.x - (float)h0); l[1] = (__bf16)(v.y - (float)h1);
+        l[2] = (__bf16)(v.z - (float)h2); l[3] = (__bf16)(v.w - (float)h3);
+        *reinterpret_cast<bf16x4 *>(q_hi + i) = h;
+        *reinterpret_cast<bf16x4 *>(q_lo + i) = l;
+    }
+}
+
+constexpr int kBfBM = 256;
+
+__global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
+                                                                 int32_t B, const float *__restrict__ E, int64_t n_rows,
+                                                                 int32_t D, float *__restrict__ S, int64_t s_stride,
                                                                  int32_t n_ntiles, int32_t n_mtiles)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 img[4][kGemmBM * kBfLd];     // A_hi, A_lo, B_hi, B_lo
+    // A_hi, A_lo: [256][72] bf16; B_hi, B_lo: [128][72] bf16  = 110,592 B, one workgroup per CU
+    extern __shared__ __attribute__((aligned(16))) __bf16 img[];
+    __bf16 *a_hi = img, *a_lo = img + kBfBM * kBfLd, *b_hi = img + 2 * kBfBM * kBfLd, *b_lo = b_hi + kGemmBN * kBfLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware order: ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
@@ -167,18 +189,34 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_bf16x3_kernel(const float *__
     const int mt = slot % n_mtiles, nt = (slot / n_mtiles) * 8 + xcd;
     if (nt >= n_ntiles) return;
     const int64_t n0 = (int64_t)nt * kGemmBN;
-    const int b0 = mt * kGemmBM;
+    const int b0 = mt * kBfBM;
 
-    const int ld_r = tid >> 4, ld_c = tid & 15;
-    float4 ra[8], rb[8];
-    auto load_stage = [&](int k0) {
+    // staging: A pieces are 16-byte (8 bf16) copies, 4 per image per thread; B pieces are float4, 4 per thread
+    const int la_r = tid >> 3, la_c = tid & 7;          // A: rows it*64 + la_r, 8-element chunk la_c
+    const int lb_r = tid >> 4, lb_c = tid & 15;         // B: rows it*32 + lb_r, float4 chunk lb_c
+    // two register sets: the loads of K-step t+2 are issued while step t is multiplied, so a
+    // load has two whole steps to land (one step of MFMAs is shorter than an HBM round trip)
+    struct Stage { bf16x8 ah[4], al[4]; float4 b[4]; };
+    Stage st0, st1;
+    auto load_stage = [&](Stage &st, int k0) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {     // clamped, never branched around (see K2)
-            const int r = it * 16 + ld_r;
+        for (int it = 0; it < 4; ++it) {                // clamped, never branched around
+            const int r = it * 64 + la_r;
             const int qr = (b0 + r < B) ? b0 + r : B - 1;
-            const int64_t er = (n0 + r < n_rows) ? n0 + r : n_rows - 1;
-            ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)qr * D + k0 + ld_c * 4);
-            rb[it] = *reinterpret_cast<const float4 *>(E + er * (int64_t)D + k0 + ld_c * 4);
+            st.ah[it] = *reinterpret_cast<const bf16x8 *>(Qh + (int64_t)qr * D + k0 + la_c * 8);
+            st.al[it] = *reinterpret_cast<const bf16x8 *>(Ql + (int64_t)qr * D + k0 + la_c * 8);
+            const int rr = it * 32 + lb_r;
+            const int64_t er = (n0 + rr < n_rows) ? n0 + rr : n_rows - 1;
+            st.b[it] = *reinterpret_cast<const float4 *>(E + er * (int64_t)D + k0 + lb_c * 4);
+        }
+    };
+    auto store_stage = [&](const Stage &st) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 64 + la_r;
+            *reinterpret_cast<bf16x8 *>(a_hi + r * kBfLd + la_c * 8) = st.ah[it];
+            *reinterpret_cast<bf16x8 *>(a_lo + r * kBfLd + la_c * 8) = st.al[it];
+            split_write(b_hi, b_lo, it * 32 + lb_r, lb_c, st.b[it]);
         }
     };
     f32x16 acc[2][2];
@@ -193,26 +231,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_bf16x3_kernel(const float *__
     const int a_off = (wm * 64 + fr) * kBfLd + fh * 8;
     const int b_off = (wn * 64 + fr) * kBfLd + fh * 8;
 
-    load_stage(0);
-    for (int k0 = 0; k0 < D; k0 += kGemmBK) {
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            split_write(img[0], img[1], it * 16 + ld_r, ld_c, ra[it]);
-            split_write(img[2], img[3], it * 16 + ld_r, ld_c, rb[it]);
-        }
-        if (k0 + kGemmBK < D) load_stage(k0 + kGemmBK);
-        __builtin_amdgcn_sched_barrier(0);                          // loads stay above the MFMA block
-        __syncthreads();
+    auto mfma_step = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {                            // 16 k per MFMA
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8 *>(img[0] + a_off + i * 32 * kBfLd + ks * 16);
-                al[i] = *reinterpret_cast<const bf16x8 *>(img[1] + a_off + i * 32 * kBfLd + ks * 16);
-                bh[i] = *reinterpret_cast<const bf16x8 *>(img[2] + b_off + i * 32 * kBfLd + ks * 16);
-                bl[i] = *reinterpret_cast<const bf16x8 *>(img[3] + b_off + i * 32 * kBfLd + ks * 16);
+                ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + a_off + i * 32 * kBfLd + ks * 16);
+                al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + a_off + i * 32 * kBfLd + ks * 16);
+                bh[i] = *reinterpret_cast<const bf16x8 *>(b_hi + b_off + i * 32 * kBfLd + ks * 16);
+                bl[i] = *reinterpret_cast<const bf16x8 *>(b_lo + b_off + i * 32 * kBfLd + ks * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -226,6 +254,26 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_bf16x3_kernel(const float *__
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int n_steps = D / kGemmBK;
+    load_stage(st0, 0);
+    if (n_steps > 1) load_stage(st1, kGemmBK);
+    for (int t = 0; t < n_steps; t += 2) {
+        __syncthreads();
+        store_stage(st0);
+        if (t + 2 < n_steps) load_stage(st0, (t + 2) * kGemmBK);
+        __builtin_amdgcn_sched_barrier(0);                          // loads stay above the MFMA block
+        __syncthreads();
+        mfma_step();
+        if (t + 1 < n_steps) {
+            __syncthreads();
+            store_stage(st1);
+            if (t + 3 < n_steps) load_stage(st1, (t + 3) * kGemmBK);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            mfma_step();
         }
     }
 #pragma unroll
@@ -242,16 +290,24 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_bf16x3_kernel(const float *__
 }
 
 hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
-                                  int64_t s_stride, hipStream_t s)
+                                  int64_t s_stride, void *q_split_ws, hipStream_t s)
 {
     if (B <= 0 || n_rows <= 0) return hipSuccess;
     if (D % kGemmBK != 0) return hipErrorInvalidValue;
+    __bf16 *q_hi = static_cast<__bf16 *>(q_split_ws), *q_lo = q_hi + (size_t)B * D;
+    const int64_t nq = (int64_t)B * D;
+    hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)std::min<int64_t>((nq / 4 + 255) / 256, 2048)), dim3(256), 0, s,
+                       Q, nq, q_hi, q_lo);
     const int64_t n_ntiles = (n_rows + kGemmBN - 1) / kGemmBN;
-    const int32_t n_mtiles = (B + kGemmBM - 1) / kGemmBM;
+    const int32_t n_mtiles = (B + kBfBM - 1) / kBfBM;
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_dot_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride,
-                       (int32_t)n_ntiles, n_mtiles);
+    constexpr size_t lds_bytes = sizeof(__bf16) * (2 * kBfBM + 2 * kGemmBN) * kBfLd;     // 110,592 B
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(gemm_dot_bf16x3_kernel, dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B, E, n_rows, D, S,
+                       s_stride, (int32_t)n_ntiles, n_mtiles);
     return hipGetLastError();
 }
 

@@ -117,8 +117,9 @@ hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_
                                int64_t s_stride, hipStream_t s);
 // K2b: the same S from three bf16 MFMA products of on-the-fly hi/lo splits (see orr_gemm.hip for
 // the error bound); D % 64 == 0.
+// q_split_ws: device scratch of 4*B*D bytes for the queries' hi/lo halves.
 hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
-                                  int64_t s_stride, hipStream_t s);
+                                  int64_t s_stride, void *q_split_ws, hipStream_t s);
 // K2s: the same for B <= 32 queries, streaming (HBM-bound) structure.
 hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                             int64_t s_stride, hipStream_t s);
