@@ -110,6 +110,14 @@ host.orrh_service_search_json.restype = C.c_int
 host.orrh_service_search_json.argtypes = [_vp, C.c_char_p, _vp, _i32, _i32, _i64, C.POINTER(_vp), C.POINTER(_i64)]
 host.orrh_free.restype = None
 host.orrh_free.argtypes = [_vp]
+host.orrh_batcher_create.restype = _vp
+host.orrh_batcher_create.argtypes = [_vp, _i32, _i32]
+host.orrh_batcher_destroy.restype = None
+host.orrh_batcher_destroy.argtypes = [_vp]
+host.orrh_batcher_search.restype = C.c_int
+host.orrh_batcher_search.argtypes = [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]
+host.orrh_batcher_stats.restype = None
+host.orrh_batcher_stats.argtypes = [_vp, _vp, _vp, _vp]
 
 EXPORTED_HIP_SYMBOLS = [
     "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",
@@ -120,7 +128,8 @@ EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_te
                          "orrh_round4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_service_create", "orrh_service_destroy",
-                         "orrh_service_search_json", "orrh_free"]
+                         "orrh_service_search_json", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
+                         "orrh_batcher_search", "orrh_batcher_stats"]
 
 
 def check(status: int) -> None:
