@@ -118,6 +118,14 @@ host.orrh_batcher_search.restype = C.c_int
 host.orrh_batcher_search.argtypes = [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]
 host.orrh_batcher_stats.restype = None
 host.orrh_batcher_stats.argtypes = [_vp, _vp, _vp, _vp]
+host.orrh_batcher_create.restype = _vp
+host.orrh_batcher_create.argtypes = [_vp, _i32, _i32]
+host.orrh_batcher_destroy.restype = None
+host.orrh_batcher_destroy.argtypes = [_vp]
+host.orrh_batcher_search.restype = C.c_int
+host.orrh_batcher_search.argtypes = [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]
+host.orrh_batcher_stats.restype = None
+host.orrh_batcher_stats.argtypes = [_vp, _vp, _vp, _vp]
 
 EXPORTED_HIP_SYMBOLS = [
     "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",

@@ -1,0 +1,181 @@
+// orr_batcher.cpp -- request micro-batcher in front of orr_search_batch
+// (include/omnirecall_host.h).  One worker thread per batcher; callers block on a
+// condition variable until their slice of the batch result is ready.
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/omnirecall_hip.h"
+#include "../../../include/omnirecall_host.h"
+
+namespace {
+
+struct Request {
+    int32_t dim;
+    const float *q;
+    const uint8_t *terms;
+    const uint32_t *term_off;
+    int32_t n_terms;
+    int64_t now_ticks;
+    int32_t topk;
+    int64_t candidate_limit;
+    int64_t *out_rows;
+    double *out_scores;
+    int32_t *out_count;
+    int status = 1;            // 1 = pending
+    bool done = false;
+};
+
+}  // namespace
+
+struct orrh_batcher {
+    orr_index *index = nullptr;
+    int32_t max_batch = 64;
+    int32_t max_wait_us = 200;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Request *> queue;
+    bool stop = false;
+    std::thread worker;
+    int64_t batches = 0, requests = 0;
+    int32_t largest = 0;
+};
+
+namespace {
+
+bool compatible(const Request *a, const Request *b)
+{
+    return a->dim == b->dim && a->now_ticks == b->now_ticks && a->candidate_limit == b->candidate_limit;
+}
+
+void run_batch(orrh_batcher *b, std::vector<Request *> &batch)
+{
+    const int32_t B = (int32_t)batch.size();
+    const int32_t dim = batch[0]->dim;
+    int32_t topk = 1;
+    for (auto r : batch) topk = std::max(topk, std::max(1, r->topk));
+    std::vector<float> q((size_t)B * (size_t)std::max(dim, 0) + 1);
+    std::vector<uint8_t> terms;
+    std::vector<uint32_t> term_off{0}, qoff{0};
+    for (int32_t i = 0; i < B; ++i) {
+        const Request *r = batch[i];
+        if (dim > 0) memcpy(q.data() + (size_t)i * dim, r->q, sizeof(float) * (size_t)dim);
+        for (int32_t t = 0; t < r->n_terms; ++t) {
+            const uint32_t o = r->term_off[t], e = r->term_off[t + 1];
+            terms.insert(terms.end(), r->terms + o, r->terms + e);
+            term_off.push_back((uint32_t)terms.size());
+        }
+        qoff.push_back((uint32_t)term_off.size() - 1);
+    }
+    terms.push_back(0);
+    std::vector<int64_t> rows((size_t)B * topk, -1);
+    std::vector<double> scores((size_t)B * topk, 0.0);
+    std::vector<int32_t> counts((size_t)B, 0);
+    const int st = orr_search_batch(b->index, B, dim, dim > 0 ? q.data() : nullptr, terms.data(), term_off.data(), qoff.data(),
+                                    batch[0]->now_ticks, topk, batch[0]->candidate_limit, rows.data(), scores.data(),
+                                    counts.data());
+    for (int32_t i = 0; i < B; ++i) {
+        Request *r = batch[i];
+        r->status = st;
+        if (st == ORR_OK) {
+            const int32_t k = std::max(1, r->topk);
+            const int32_t n = std::min(k, counts[i]);          // a smaller topk is a prefix of the batch's
+            for (int32_t j = 0; j < k; ++j) {
+                r->out_rows[j] = j < n ? rows[(size_t)i * topk + j] : -1;
+                r->out_scores[j] = j < n ? scores[(size_t)i * topk + j] : 0.0;
+            }
+            if (r->out_count) *r->out_count = n;
+        }
+    }
+}
+
+void worker_loop(orrh_batcher *b)
+{
+    std::unique_lock<std::mutex> lk(b->mu);
+    for (;;) {
+        b->cv_work.wait(lk, [b] { return b->stop || !b->queue.empty(); });
+        if (b->stop && b->queue.empty()) return;
+        // collect: the head request and every compatible one that shows up within the window
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->max_wait_us);
+        std::vector<Request *> batch;
+        for (;;) {
+            for (auto it = b->queue.begin(); it != b->queue.end() && (int32_t)batch.size() < b->max_batch;) {
+                if (batch.empty() || compatible(batch[0], *it)) {
+                    batch.push_back(*it);
+                    it = b->queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            if ((int32_t)batch.size() >= b->max_batch || b->stop) break;
+            if (b->cv_work.wait_until(lk, deadline) == std::cv_status::timeout) break;
+        }
+        lk.unlock();
+        run_batch(b, batch);
+        lk.lock();
+        b->batches += 1;
+        b->requests += (int64_t)batch.size();
+        b->largest = std::max(b->largest, (int32_t)batch.size());
+        for (auto r : batch) r->done = true;
+        b->cv_done.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+orrh_batcher *orrh_batcher_create(void *index, int32_t max_batch, int32_t max_wait_us)
+{
+    if (!index || max_batch < 1 || max_wait_us < 0) return nullptr;
+    orrh_batcher *b = new orrh_batcher();
+    b->index = static_cast<orr_index *>(index);
+    b->max_batch = max_batch;
+    b->max_wait_us = max_wait_us;
+    b->worker = std::thread(worker_loop, b);
+    return b;
+}
+
+void orrh_batcher_destroy(orrh_batcher *b)
+{
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> l(b->mu);
+        b->stop = true;
+    }
+    b->cv_work.notify_all();
+    if (b->worker.joinable()) b->worker.join();
+    delete b;
+}
+
+int orrh_batcher_search(orrh_batcher *b, int32_t dim, const float *q, const uint8_t *terms_utf8, const uint32_t *term_off,
+                        int32_t n_terms, int64_t now_ticks, int32_t topk, int64_t candidate_limit, int64_t *out_rows,
+                        double *out_scores, int32_t *out_count)
+{
+    if (!b || !out_rows || !out_scores || dim < 0 || n_terms < 0 || (dim > 0 && !q) || (n_terms > 0 && (!terms_utf8 || !term_off)))
+        return ORR_EINVAL;
+    Request r{dim, q, terms_utf8, term_off, n_terms, now_ticks, topk, candidate_limit, out_rows, out_scores, out_count};
+    std::unique_lock<std::mutex> lk(b->mu);
+    if (b->stop) return ORR_ESTATE;
+    b->queue.push_back(&r);
+    b->cv_work.notify_one();
+    b->cv_done.wait(lk, [&r] { return r.done; });
+    return r.status;
+}
+
+void orrh_batcher_stats(orrh_batcher *b, int64_t *batches, int64_t *requests, int32_t *largest_batch)
+{
+    if (!b) return;
+    std::lock_guard<std::mutex> l(b->mu);
+    if (batches) *batches = b->batches;
+    if (requests) *requests = b->requests;
+    if (largest_batch) *largest_batch = b->largest;
+}
+
+}  // extern "C"

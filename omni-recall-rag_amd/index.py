@@ -165,3 +165,40 @@ def merge_candidates(all_records: np.ndarray, index_dim: int, qvecs, queries_ter
                                        now_ticks, int(topk), _ptr(rows), _ptr(scores), _ptr(counts),
                                        C.cast(C.byref(unc), C.c_void_p)))
     return rows, scores, counts, int(unc.value)
+
+
+class MicroBatcher:
+    """orrh_batcher: coalesces concurrent single-query searches on one RecallIndex into batched
+    orr_search_batch calls (include/omnirecall_host.h).  search() blocks and is thread-safe
+    (ctypes releases the GIL during the call)."""
+
+    def __init__(self, index: RecallIndex, max_batch: int = 64, max_wait_us: int = 200):
+        self._index = index                    # keep the index alive
+        self._h = C.c_void_p(N.host.orrh_batcher_create(index._h, max_batch, max_wait_us))
+        if not self._h:
+            raise ValueError("orrh_batcher_create failed")
+
+    def search(self, qvec, terms: Sequence[bytes], now_ticks: int, topk: int, candidate_limit: int = 300):
+        q = None if qvec is None else np.ascontiguousarray(qvec, dtype=np.float32).reshape(-1)
+        dim = 0 if q is None else int(q.shape[0])
+        pool, toff, _ = pack_terms([terms])
+        k = max(1, int(topk))
+        rows = np.full(k, -1, dtype=np.int64)
+        scores = np.zeros(k, dtype=np.float64)
+        cnt = C.c_int32(0)
+        st = N.host.orrh_batcher_search(self._h, dim, _ptr(q) if dim else None, _ptr(pool), _ptr(toff), len(terms),
+                                        now_ticks, int(topk), int(candidate_limit), _ptr(rows), _ptr(scores),
+                                        C.cast(C.byref(cnt), C.c_void_p))
+        N.check(st)
+        return rows[:cnt.value], scores[:cnt.value]
+
+    def stats(self):
+        b, r, l = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        N.host.orrh_batcher_stats(self._h, C.cast(C.byref(b), C.c_void_p), C.cast(C.byref(r), C.c_void_p),
+                                  C.cast(C.byref(l), C.c_void_p))
+        return {"batches": b.value, "requests": r.value, "largest_batch": l.value}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.host.orrh_batcher_destroy(self._h)
+            self._h = None

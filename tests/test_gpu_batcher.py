@@ -1,0 +1,69 @@
+"""Micro-batcher: many request threads, one query each, coalesced into batched
+orr_search_batch calls; every caller must get exactly what a lone search returns, and concurrent
+un-batched searches from several threads must be safe too (per-index serialisation)."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import NOW, build_index, oracle_corpus, pkg, random_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_requests_are_batched_and_exact():
+    P = pkg()
+    rng = np.random.default_rng(17)
+    n, dim = 4000, 128
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    n_req = 96
+    qs = rng.standard_normal((n_req, dim)).astype(np.float32)
+    texts = [["alpha kubernetes", "the helm", "GAMMA delta zzz", "net ab"][i % 4] for i in range(n_req)]
+    topks = [[10, 3, 12, 1][i % 4] for i in range(n_req)]
+    batcher = P.MicroBatcher(idx, max_batch=32, max_wait_us=20000)
+    results = [None] * n_req
+    barrier = threading.Barrier(n_req)
+
+    def work(i):
+        barrier.wait()
+        results[i] = batcher.search(qs[i], P.text.query_terms(texts[i]), NOW, topks[i], candidate_limit=n)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_req)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    st = batcher.stats()
+    assert st["requests"] == n_req and st["batches"] < n_req and st["largest_batch"] > 1, st
+    for i in range(n_req):
+        orow, osc, _ = corpus.search(qs[i], texts[i], NOW, topks[i], candidate_limit=n)
+        rows, scores = results[i]
+        assert list(rows) == list(orow) and np.array_equal(scores, osc), i
+    batcher.close()
+    idx.close()
+
+
+def test_concurrent_unbatched_searches_are_serialised_safely():
+    P = pkg()
+    rng = np.random.default_rng(18)
+    n, dim = 3000, 64
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    qs = rng.standard_normal((24, dim)).astype(np.float32)
+    out = [None] * 24
+
+    def work(i):
+        out[i] = idx.search(qs[i:i + 1], [P.text.query_terms("alpha beta")], NOW, 5, candidate_limit=n)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(24):
+        orow, osc, _ = corpus.search(qs[i], "alpha beta", NOW, 5, candidate_limit=n)
+        assert list(out[i][0][0]) == list(orow) and np.array_equal(out[i][1][0], osc)
+    idx.close()
