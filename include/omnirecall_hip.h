@@ -173,6 +173,15 @@ int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_
                          int64_t *out_rows, double *out_scores, int32_t *out_counts,
                          int32_t *out_uncertified);
 
+/* ---- shard file ---------------------------------------------
+ * A sealed shard as one binary file (embeddings, exact norms, timestamps, row ids and the
+ * token index), so that a corpus does not have to be re-ingested and re-sealed per run.
+ * The reference's only durable form is Cosmos JSON (CosmosIngestionRecords.cs:19-30).
+ * load: cfg->device and cfg->row_base are taken from cfg; dim comes from the file
+ * (cfg->dim must be 0 or equal).  The loaded index is sealed. */
+int orr_index_save(orr_index *idx, const char *path);
+int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
+
 /* ---- measurement ---------------------------------------------------------*/
 int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets the counters */
 int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap);  /* returns count */

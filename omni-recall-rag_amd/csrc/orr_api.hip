@@ -624,6 +624,155 @@ int orr_index_seal(orr_index *idx)
     return ORR_OK;
 }
 
+namespace {
+
+struct ShardHeader {
+    char magic[8];               // "ORRSHD1\0"
+    uint32_t version, dim;
+    int64_t n_rows, n_tokens;
+    uint64_t n_postings, vpool_bytes;
+    uint64_t reserved[4];
+};
+constexpr size_t kIoChunk = 64u << 20;
+
+int write_device_array(FILE *f, const void *dptr, size_t bytes, std::vector<uint8_t> &buf)
+{
+    const uint8_t *p = static_cast<const uint8_t *>(dptr);
+    for (size_t off = 0; off < bytes; off += kIoChunk) {
+        const size_t m = std::min(kIoChunk, bytes - off);
+        HIP_TRY(hipMemcpy(buf.data(), p + off, m, hipMemcpyDeviceToHost));
+        if (fwrite(buf.data(), 1, m, f) != m) return fail(ORR_EINVAL, "short write to the shard file");
+    }
+    return ORR_OK;
+}
+
+int read_device_array(FILE *f, void *dptr, size_t bytes, std::vector<uint8_t> &buf)
+{
+    uint8_t *p = static_cast<uint8_t *>(dptr);
+    for (size_t off = 0; off < bytes; off += kIoChunk) {
+        const size_t m = std::min(kIoChunk, bytes - off);
+        if (fread(buf.data(), 1, m, f) != m) return fail(ORR_EINVAL, "shard file is truncated");
+        HIP_TRY(hipMemcpy(p + off, buf.data(), m, hipMemcpyHostToDevice));
+    }
+    return ORR_OK;
+}
+
+}  // namespace
+
+int orr_index_save(orr_index *idx, const char *path)
+{
+    if (!idx || !path) return fail(ORR_EINVAL, "orr_index_save: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_save: index is not sealed");
+    ORR_TRY(bind_device(idx));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(ORR_EINVAL, "orr_index_save: cannot open %s", path);
+    ShardHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "ORRSHD1", 8);
+    h.version = 1; h.dim = (uint32_t)idx->dim; h.n_rows = idx->n_rows; h.n_tokens = idx->n_tokens;
+    h.n_postings = idx->n_postings;
+    uint64_t vpool_bytes = 0;
+    std::vector<uint64_t> vstart((size_t)idx->n_tokens);
+    std::vector<uint32_t> vlen((size_t)idx->n_tokens);
+    if (idx->n_tokens > 0) {
+        hipError_t e1 = hipMemcpy(vstart.data(), idx->d_vstart, sizeof(uint64_t) * vstart.size(), hipMemcpyDeviceToHost);
+        hipError_t e2 = hipMemcpy(vlen.data(), idx->d_vlen, sizeof(uint32_t) * vlen.size(), hipMemcpyDeviceToHost);
+        if (e1 != hipSuccess || e2 != hipSuccess) { fclose(f); return fail(ORR_EDEVICE, "orr_index_save: device copy failed"); }
+        vpool_bytes = vstart.back() + orr::padded_row_bytes(vlen.back());
+    }
+    h.vpool_bytes = vpool_bytes;
+    std::vector<uint8_t> buf(kIoChunk);
+    const size_t n = (size_t)idx->n_rows, V = (size_t)idx->n_tokens;
+    int r = fwrite(&h, sizeof(h), 1, f) == 1 ? ORR_OK : fail(ORR_EINVAL, "short write to the shard file");
+    if (r == ORR_OK && idx->dim > 0) r = write_device_array(f, idx->d_emb, sizeof(float) * n * idx->dim, buf);
+    if (r == ORR_OK) r = write_device_array(f, idx->d_norm_b, sizeof(double) * n, buf);
+    if (r == ORR_OK) r = write_device_array(f, idx->d_created, sizeof(int64_t) * n, buf);
+    if (r == ORR_OK) r = write_device_array(f, idx->d_row_ids, sizeof(int64_t) * n, buf);
+    if (r == ORR_OK && n) r = fwrite(idx->h_clen.data(), sizeof(uint32_t), n, f) == n ? ORR_OK : fail(ORR_EINVAL, "short write");
+    if (r == ORR_OK && V) {
+        r = fwrite(vstart.data(), sizeof(uint64_t), V, f) == V && fwrite(vlen.data(), sizeof(uint32_t), V, f) == V
+                ? ORR_OK : fail(ORR_EINVAL, "short write");
+        if (r == ORR_OK) r = write_device_array(f, idx->d_vpool, vpool_bytes, buf);
+    }
+    if (r == ORR_OK && n) r = write_device_array(f, idx->d_post_off, sizeof(uint64_t) * (V + 1), buf);
+    if (r == ORR_OK && idx->n_postings) r = write_device_array(f, idx->d_post_rows, sizeof(uint32_t) * (size_t)idx->n_postings, buf);
+    if (fclose(f) != 0 && r == ORR_OK) r = fail(ORR_EINVAL, "orr_index_save: close failed");
+    return r;
+}
+
+int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
+{
+    if (!cfg || !path || !out) return fail(ORR_EINVAL, "orr_index_load: null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ORR_EINVAL, "orr_index_load: cannot open %s", path);
+    ShardHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "ORRSHD1", 8) != 0 || h.version != 1 || h.n_rows < 0 || h.n_tokens < 0) {
+        fclose(f);
+        return fail(ORR_EINVAL, "orr_index_load: %s is not a version-1 shard file", path);
+    }
+    if (cfg->dim != 0 && cfg->dim != (int32_t)h.dim) {
+        fclose(f);
+        return fail(ORR_EDIM, "orr_index_load: file dimension %u differs from the requested %d", h.dim, cfg->dim);
+    }
+    orr_config c = *cfg;
+    c.dim = (int32_t)h.dim;
+    c.capacity_rows = h.n_rows;
+    orr_index *idx = nullptr;
+    int r = orr_index_create(&c, &idx);
+    if (r != ORR_OK) { fclose(f); return r; }
+    // idx is private to this call until it is returned: no locking needed
+    const size_t n = (size_t)h.n_rows, V = (size_t)h.n_tokens;
+    std::vector<uint8_t> buf(kIoChunk);
+    idx->n_rows = h.n_rows; idx->n_tokens = h.n_tokens; idx->n_postings = h.n_postings;
+    auto body = [&]() -> int {
+        if (idx->dim > 0) ORR_TRY(read_device_array(f, idx->d_emb, sizeof(float) * n * idx->dim, buf));
+        ORR_TRY(dev_alloc(&idx->d_norm_b, std::max<size_t>(n, 1)));
+        ORR_TRY(read_device_array(f, idx->d_norm_b, sizeof(double) * n, buf));
+        idx->h_created.resize(n);
+        const long pos = ftell(f);
+        if (n && fread(idx->h_created.data(), sizeof(int64_t), n, f) != n) return fail(ORR_EINVAL, "shard file is truncated");
+        fseek(f, pos, SEEK_SET);
+        ORR_TRY(read_device_array(f, idx->d_created, sizeof(int64_t) * n, buf));
+        ORR_TRY(read_device_array(f, idx->d_row_ids, sizeof(int64_t) * n, buf));
+        idx->h_clen.resize(n);
+        if (n && fread(idx->h_clen.data(), sizeof(uint32_t), n, f) != n) return fail(ORR_EINVAL, "shard file is truncated");
+        idx->h_cprefix.assign(n + 1, 0);
+        for (size_t p = 0; p < n; ++p) idx->h_cprefix[p + 1] = idx->h_cprefix[p] + idx->h_clen[p];
+        if (V) {
+            ORR_TRY(dev_alloc(&idx->d_vstart, V));
+            ORR_TRY(dev_alloc(&idx->d_vlen, V));
+            ORR_TRY(dev_alloc(&idx->d_vpool, (size_t)h.vpool_bytes + orr::kScanPoolSlack));
+            ORR_TRY(read_device_array(f, idx->d_vstart, sizeof(uint64_t) * V, buf));
+            ORR_TRY(read_device_array(f, idx->d_vlen, sizeof(uint32_t) * V, buf));
+            HIP_TRY(hipMemset(idx->d_vpool, 0x20, (size_t)h.vpool_bytes + orr::kScanPoolSlack));
+            ORR_TRY(read_device_array(f, idx->d_vpool, (size_t)h.vpool_bytes, buf));
+        }
+        if (n) {
+            ORR_TRY(dev_alloc(&idx->d_post_off, V + 1));
+            ORR_TRY(read_device_array(f, idx->d_post_off, sizeof(uint64_t) * (V + 1), buf));
+        }
+        ORR_TRY(dev_alloc(&idx->d_post_rows, std::max<size_t>((size_t)h.n_postings, 1)));
+        if (h.n_postings) ORR_TRY(read_device_array(f, idx->d_post_rows, sizeof(uint32_t) * (size_t)h.n_postings, buf));
+        return ORR_OK;
+    };
+    r = body();
+    fclose(f);
+    if (r != ORR_OK) {
+        const std::string keep = g_last_error;
+        orr_index_destroy(idx);
+        g_last_error = keep;
+        return r;
+    }
+    // the raw content buffers of an unsealed index are not part of a shard file
+    if (idx->d_cstart) { (void)hipFree(idx->d_cstart); idx->d_cstart = nullptr; }
+    if (idx->d_clen) { (void)hipFree(idx->d_clen); idx->d_clen = nullptr; }
+    idx->sealed = true;
+    *out = idx;
+    return ORR_OK;
+}
+
 int orr_index_set_profiling(orr_index *idx, int32_t enabled)
 {
     if (!idx) return fail(ORR_EINVAL, "null index");

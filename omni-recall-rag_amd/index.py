@@ -98,6 +98,22 @@ class RecallIndex:
     def seal(self) -> None:
         N.check(N.hip.orr_index_seal(self._h))
 
+    def save(self, path: str) -> None:
+        """orr_index_save: the sealed shard as one binary file."""
+        N.check(N.hip.orr_index_save(self._h, path.encode()))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0, row_base: int = 0) -> "RecallIndex":
+        """orr_index_load: a sealed shard from a file written by save()."""
+        cfg = N.OrrConfig(C.sizeof(N.OrrConfig), device, 0, 0, 0, row_base)
+        h = C.c_void_p()
+        N.check(N.hip.orr_index_load(C.byref(cfg), path.encode(), C.byref(h)))
+        self = cls.__new__(cls)
+        self._h = h
+        self.dim = int(N.hip.orr_index_dim(h))
+        self.row_base = row_base
+        return self
+
     @staticmethod
     def _query_args(qvecs, n_queries: int):
         if qvecs is None:

@@ -271,3 +271,39 @@ def test_gemm_candidate_dots_are_within_the_stated_bound():
             assert c["dot"] == orc.dot(qs[b], emb[r])          # after K6 the record holds the exact dot
         assert rec[b, 64]["dot"] > 0                            # trailer carries the pass's epsilon
     idx.close()
+
+
+def test_shard_file_round_trip(tmp_path):
+    """orr_index_save / orr_index_load: the reloaded shard answers exactly like the original
+    (exact path, batched MFMA path, keyword-only, large k), and bad files are rejected."""
+    P = pkg()
+    rng = np.random.default_rng(41)
+    n, dim = 2500, 128
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c)
+    path = str(tmp_path / "shard.orr")
+    idx.save(path)
+    re = P.RecallIndex.load(path)
+    assert re.rows == n and re.dim == dim
+    corpus = oracle_corpus(c)
+    q = rng.standard_normal(dim).astype(np.float32)
+    for topk, limit in ((10, n), (5, 300), (70, n)):
+        assert_same_ranking(re, corpus, c, q, "alpha kubernetes the", topk, limit)
+        assert_same_ranking(re, corpus, c, None, "GAMMA delta", topk, limit)
+    B = 20
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    terms = [P.text.query_terms("helm azure")] * B
+    r1 = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    r2 = re.search(qs, terms, NOW, 10, candidate_limit=n)
+    assert all(np.array_equal(a, b) for a, b in zip(r1, r2))
+    bad = tmp_path / "bad.orr"
+    bad.write_bytes(b"not a shard file at all" * 10)
+    with pytest.raises(P.OrrError) as ei:
+        P.RecallIndex.load(str(bad))
+    assert ei.value.code == P.native.ORR_EINVAL
+    trunc = tmp_path / "trunc.orr"
+    trunc.write_bytes(open(path, "rb").read()[:4096])
+    with pytest.raises(P.OrrError):
+        P.RecallIndex.load(str(trunc))
+    idx.close()
+    re.close()
