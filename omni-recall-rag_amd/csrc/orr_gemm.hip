@@ -174,29 +174,33 @@ __global__ __launch_bounds__(256) void split_queries_kernel(const float *__restr
 
 constexpr int kBfBM = 256;
 
+// NT = 32-column MFMA tiles per wave along the rows of E: the workgroup tile is 256 queries x
+// (64 NT) rows.  NT = 4 (256 x 256, 144 KiB of LDS, 128 accumulator VGPRs, one-step prefetch)
+// halves the staging work per MFMA of NT = 2 (256 x 128, two-step prefetch).
+template <int NT, bool TWO_STAGE>
 __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
                                                                  int32_t B, const float *__restrict__ E, int64_t n_rows,
                                                                  int32_t D, float *__restrict__ S, int64_t s_stride,
                                                                  int32_t n_ntiles, int32_t n_mtiles)
 {
-    // A_hi, A_lo: [256][72] bf16; B_hi, B_lo: [128][72] bf16  = 110,592 B, one workgroup per CU
+    constexpr int BN = 64 * NT;
+    constexpr int NB = BN / 32;                         // float4 row pieces of the E tile per thread
+    // A_hi, A_lo: [256][72] bf16; B_hi, B_lo: [BN][72] bf16
     extern __shared__ __attribute__((aligned(16))) __bf16 img[];
-    __bf16 *a_hi = img, *a_lo = img + kBfBM * kBfLd, *b_hi = img + 2 * kBfBM * kBfLd, *b_lo = b_hi + kGemmBN * kBfLd;
+    __bf16 *a_hi = img, *a_lo = img + kBfBM * kBfLd, *b_hi = img + 2 * kBfBM * kBfLd, *b_lo = b_hi + BN * kBfLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware order: ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int mt = slot % n_mtiles, nt = (slot / n_mtiles) * 8 + xcd;
     if (nt >= n_ntiles) return;
-    const int64_t n0 = (int64_t)nt * kGemmBN;
+    const int64_t n0 = (int64_t)nt * BN;
     const int b0 = mt * kBfBM;
 
-    // staging: A pieces are 16-byte (8 bf16) copies, 4 per image per thread; B pieces are float4, 4 per thread
+    // staging: A pieces are 16-byte (8 bf16) copies, 4 per image per thread; B pieces are float4
     const int la_r = tid >> 3, la_c = tid & 7;          // A: rows it*64 + la_r, 8-element chunk la_c
     const int lb_r = tid >> 4, lb_c = tid & 15;         // B: rows it*32 + lb_r, float4 chunk lb_c
-    // two register sets: the loads of K-step t+2 are issued while step t is multiplied, so a
-    // load has two whole steps to land (one step of MFMAs is shorter than an HBM round trip)
-    struct Stage { bf16x8 ah[4], al[4]; float4 b[4]; };
+    struct Stage { bf16x8 ah[4], al[4]; float4 b[NB]; };
     Stage st0, st1;
     auto load_stage = [&](Stage &st, int k0) {
 #pragma unroll
@@ -205,6 +209,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
             const int qr = (b0 + r < B) ? b0 + r : B - 1;
             st.ah[it] = *reinterpret_cast<const bf16x8 *>(Qh + (int64_t)qr * D + k0 + la_c * 8);
             st.al[it] = *reinterpret_cast<const bf16x8 *>(Ql + (int64_t)qr * D + k0 + la_c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
             const int rr = it * 32 + lb_r;
             const int64_t er = (n0 + rr < n_rows) ? n0 + rr : n_rows - 1;
             st.b[it] = *reinterpret_cast<const float4 *>(E + er * (int64_t)D + k0 + lb_c * 4);
@@ -216,61 +223,78 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
             const int r = it * 64 + la_r;
             *reinterpret_cast<bf16x8 *>(a_hi + r * kBfLd + la_c * 8) = st.ah[it];
             *reinterpret_cast<bf16x8 *>(a_lo + r * kBfLd + la_c * 8) = st.al[it];
-            split_write(b_hi, b_lo, it * 32 + lb_r, lb_c, st.b[it]);
         }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) split_write(b_hi, b_lo, it * 32 + lb_r, lb_c, st.b[it]);
     };
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
     const int a_off = (wm * 64 + fr) * kBfLd + fh * 8;
-    const int b_off = (wn * 64 + fr) * kBfLd + fh * 8;
+    const int b_off = (wn * 32 * NT + fr) * kBfLd + fh * 8;
 
     auto mfma_step = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {                            // 16 k per MFMA
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[2], al[2], bh[NT], bl[NT];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + a_off + i * 32 * kBfLd + ks * 16);
                 al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + a_off + i * 32 * kBfLd + ks * 16);
-                bh[i] = *reinterpret_cast<const bf16x8 *>(b_hi + b_off + i * 32 * kBfLd + ks * 16);
-                bl[i] = *reinterpret_cast<const bf16x8 *>(b_lo + b_off + i * 32 * kBfLd + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8 *>(b_hi + b_off + j * 32 * kBfLd + ks * 16);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + b_off + j * 32 * kBfLd + ks * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
         }
     };
 
     const int n_steps = D / kGemmBK;
-    load_stage(st0, 0);
-    if (n_steps > 1) load_stage(st1, kGemmBK);
-    for (int t = 0; t < n_steps; t += 2) {
-        __syncthreads();
-        store_stage(st0);
-        if (t + 2 < n_steps) load_stage(st0, (t + 2) * kGemmBK);
-        __builtin_amdgcn_sched_barrier(0);                          // loads stay above the MFMA block
-        __syncthreads();
-        mfma_step();
-        if (t + 1 < n_steps) {
+    if (TWO_STAGE) {
+        // two register sets: the loads of K-step t+2 are issued while step t is multiplied
+        load_stage(st0, 0);
+        if (n_steps > 1) load_stage(st1, kGemmBK);
+        for (int t = 0; t < n_steps; t += 2) {
             __syncthreads();
-            store_stage(st1);
-            if (t + 3 < n_steps) load_stage(st1, (t + 3) * kGemmBK);
+            store_stage(st0);
+            if (t + 2 < n_steps) load_stage(st0, (t + 2) * kGemmBK);
+            __builtin_amdgcn_sched_barrier(0);                      // loads stay above the MFMA block
+            __syncthreads();
+            mfma_step();
+            if (t + 1 < n_steps) {
+                __syncthreads();
+                store_stage(st1);
+                if (t + 3 < n_steps) load_stage(st1, (t + 3) * kGemmBK);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                mfma_step();
+            }
+        }
+    } else {
+        load_stage(st0, 0);
+        for (int t = 0; t < n_steps; ++t) {
+            __syncthreads();
+            store_stage(st0);
+            if (t + 1 < n_steps) load_stage(st0, (t + 1) * kGemmBK);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             mfma_step();
@@ -279,14 +303,32 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = n0 + wn * 64 + j * 32 + fr;
+        for (int j = 0; j < NT; ++j) {
+            const int64_t col = n0 + wn * 32 * NT + j * 32 + fr;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                 if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
             }
         }
+}
+
+template <int NT, bool TWO_STAGE>
+static hipError_t launch_bf16x3_variant(const __bf16 *q_hi, const __bf16 *q_lo, int32_t B, const float *E, int64_t n_rows,
+                                        int32_t D, float *S, int64_t s_stride, hipStream_t s)
+{
+    constexpr int BN = 64 * NT;
+    const int64_t n_ntiles = (n_rows + BN - 1) / BN;
+    const int32_t n_mtiles = (B + kBfBM - 1) / kBfBM;
+    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    constexpr size_t lds_bytes = sizeof(__bf16) * (2 * kBfBM + 2 * BN) * kBfLd;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel<NT, TWO_STAGE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((gemm_dot_bf16x3_kernel<NT, TWO_STAGE>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B, E,
+                       n_rows, D, S, s_stride, (int32_t)n_ntiles, n_mtiles);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
@@ -298,17 +340,9 @@ hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int
     const int64_t nq = (int64_t)B * D;
     hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)std::min<int64_t>((nq / 4 + 255) / 256, 2048)), dim3(256), 0, s,
                        Q, nq, q_hi, q_lo);
-    const int64_t n_ntiles = (n_rows + kGemmBN - 1) / kGemmBN;
-    const int32_t n_mtiles = (B + kBfBM - 1) / kBfBM;
-    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
-    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    constexpr size_t lds_bytes = sizeof(__bf16) * (2 * kBfBM + 2 * kGemmBN) * kBfLd;     // 110,592 B
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gemm_dot_bf16x3_kernel, dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B, E, n_rows, D, S,
-                       s_stride, (int32_t)n_ntiles, n_mtiles);
-    return hipGetLastError();
+    static const int variant = [] { const char *e = getenv("ORR_BF16_TILE"); return e ? atoi(e) : 256; }();
+    if (variant == 128) return launch_bf16x3_variant<2, true>(q_hi, q_lo, B, E, n_rows, D, S, s_stride, s);
+    return launch_bf16x3_variant<4, false>(q_hi, q_lo, B, E, n_rows, D, S, s_stride, s);
 }
 
 // K2 v2: same tile and LDS image, but the image is DOUBLE-BUFFERED (139 KiB: one workgroup

@@ -151,3 +151,40 @@ def test_service_matches_oracle_on_a_multi_document_store():
         chunks_flat = remaining
         sut.close()
     store.close()
+
+
+@pytest.mark.gpu
+def test_chat_evidence_guard_consumer_sees_the_same_scores():
+    """ChatOrchestrationService.HasSufficientEvidence (ChatOrchestrationService.cs:58-65) gates the LLM call on
+    'citation count >= minimum and some Citation.Score >= 0.25' (appsettings.json:13-16), and the prompt prints
+    score={c.Score:F4} (:85).  Both read the ROUNDED scores of this path, so the decision and the text must be
+    what the oracle's scores give."""
+    S = _svc()
+    rng = np.random.default_rng(8)
+    store = S.InMemoryIngestionStore()
+    chunks = []
+    for d in range(12):
+        created = NOW - int(rng.integers(0, 90)) * 864000000000
+        store.UpsertDocument(S.CosmosDocumentRecord("d%d" % d, "f%d.md" % d, created))
+        cs = [S.CosmosChunkRecord("d%d:%04d" % (d, i), "d%d" % d, i, " ".join(rng.choice(["alpha", "beta", "gamma"], 6)),
+                                  rng.standard_normal(16).astype(np.float32), created) for i in range(5)]
+        store.UpsertChunks(cs)
+        chunks += cs
+    cor = orc.OracleCorpus([c.Embedding for c in chunks], [c.CreatedAtTicks for c in chunks], [c.Content for c in chunks])
+
+    def guard(scores, min_citations=1, min_score=0.25):
+        return len(scores) >= min_citations and any(s >= min_score for s in scores)
+
+    for trial in range(12):
+        qv = (rng.standard_normal(16) * (0.05 if trial % 3 == 0 else 1.0)).astype(np.float32)
+        if trial % 4 == 0:
+            qv = chunks[trial].Embedding                       # cosine 1: clearly above the threshold
+        sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=300, now_ticks=NOW)
+        body = sut.Search("zeta" if trial % 2 else "alpha zeta", 5)
+        got = [c["score"] for c in body["citations"]]
+        _, _, rounded = cor.search(qv, "zeta" if trial % 2 else "alpha zeta", NOW, 5, candidate_limit=300)
+        assert got == list(rounded)
+        assert guard(got) == guard(list(rounded))
+        assert ["%.4f" % s for s in got] == ["%.4f" % s for s in rounded]      # score={c.Score:F4}
+        sut.close()
+    store.close()
