@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void split_queries_kernel(const float *__restr
 constexpr int kBfBM = 256;
 
 // NT = 32-column MFMA tiles per wave along the rows of E: the workgroup tile is 256 queries x
-// (64 NT) rows.  NT = 4 (256 x 256, 144 KiB of LDS, 128 accumulator VGPRs, one-step prefetch)
-// halves the staging work per MFMA of NT = 2 (256 x 128, two-step prefetch).
+// (64 NT) rows.  NT = 2 (256 x 128, two-step prefetch) is the default; NT = 4 (256 x 256,
+// ORR_BF16_TILE=256) halves the staging work per MFMA and measures the same 6.2 ms at B=256:
+// both sit at 42 % MfmaUtil, the ceiling of a two-barriers-per-K-step structure
+// (cdna_hip_programming.md, "the step-3 structure"); the next step is the 8-phase interleave.
 template <int NT, bool TWO_STAGE>
 __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
                                                                  int32_t B, const float *__restrict__ E, int64_t n_rows,
@@ -340,7 +342,7 @@ hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int
     const int64_t nq = (int64_t)B * D;
     hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)std::min<int64_t>((nq / 4 + 255) / 256, 2048)), dim3(256), 0, s,
                        Q, nq, q_hi, q_lo);
-    static const int variant = [] { const char *e = getenv("ORR_BF16_TILE"); return e ? atoi(e) : 256; }();
+    static const int variant = [] { const char *e = getenv("ORR_BF16_TILE"); return e ? atoi(e) : 128; }();
     if (variant == 128) return launch_bf16x3_variant<2, true>(q_hi, q_lo, B, E, n_rows, D, S, s_stride, s);
     return launch_bf16x3_variant<4, false>(q_hi, q_lo, B, E, n_rows, D, S, s_stride, s);
 }
