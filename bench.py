@@ -112,7 +112,10 @@ def main():
     rows, dim, B_local, k = args.rows_per_gpu, args.dim, args.batch, args.topk
     n_total = rows * world
     idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev)
-    front = sharded.ShardedRecallSearch(idx, dim, dev) if world > 1 else None
+    # ORR_BENCH_FORCE_SHARDED=1 drives the sharded front-end (device tensors in, records out, host
+    # merge) even on one GPU: a rehearsal of the N>1 code path without RCCL
+    use_front = world > 1 or os.environ.get("ORR_BENCH_FORCE_SHARDED") == "1"
+    front = sharded.ShardedRecallSearch(idx, dim, dev) if use_front else None
 
     n_steps_total = args.warmup + args.steps
     # queries for every step, generated up front and resident in HBM (rank r originates queries
@@ -125,7 +128,7 @@ def main():
     torch.cuda.synchronize()
 
     def step(s):
-        if world > 1:
+        if front is not None:
             return front.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, n_total)
         return idx.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
 

@@ -80,8 +80,9 @@ class ShardedRecallSearch:
             allq = send
         B = W * B_local
         q_all = allq[:, :vec_bytes].contiguous().view(torch.float32).reshape(B, dim) if dim else None
-        tall = allq[:, vec_bytes:].cpu().numpy()
-        terms_all = [_unpack_terms_fixed(tall[b]) for b in range(B)]
+        allq_host = allq.cpu().numpy()              # ONE download: vectors (for the exact normA) + terms
+        q_host = np.ascontiguousarray(allq_host[:, :vec_bytes]).view(np.float32).reshape(B, dim) if dim else None
+        terms_all = [_unpack_terms_fixed(allq_host[b, vec_bytes:]) for b in range(B)]
 
         while True:
             # ---- local scoring of every query against this shard
@@ -97,7 +98,6 @@ class ShardedRecallSearch:
             recs = allrec.cpu().numpy().view(CAND_DTYPE).reshape(W, B, kprime + 1)
             # Every rank finishes EVERY query from the same gathered bytes, so all ranks reach the
             # same "escalate or not" decision without another collective.
-            q_host = q_all.cpu().numpy() if dim else None
             rows, scores, counts, unc = merge_candidates(recs, self.index_dim, q_host, terms_all, now_ticks, topk)
             lo = self.rank * B_local
             rows, scores, counts = rows[lo:lo + B_local], scores[lo:lo + B_local], counts[lo:lo + B_local]
