@@ -122,6 +122,9 @@ int orr_index_append(orr_index *idx, int64_t n, int32_t dim, const float *emb,
  * OrderByDescending(c => c.CreatedAtUtc) yields (InMemoryIngestionStore.cs:61) --
  * and precomputes the exact row norms.  Required before searching. */
 int     orr_index_seal(orr_index *idx);
+/* Moves the shard within the global candidate order (a newer shard was put in front of it):
+ * only order keys and the clipping of candidate_limit depend on it. */
+int     orr_index_set_row_base(orr_index *idx, int64_t row_base);
 int64_t orr_index_rows(const orr_index *idx);
 int32_t orr_index_dim(const orr_index *idx);
 

@@ -72,6 +72,13 @@ int64_t orrh_store_chunk_count(const orrh_store *s);
 /* candidate_limit = GetRecentChunksAsync(maxCount) (300 in the reference). */
 orrh_service *orrh_service_create(orrh_store *s, int32_t device, int64_t candidate_limit);
 void          orrh_service_destroy(orrh_service *svc);
+/* Index maintenance: documents uploaded after the last build whose chunks are
+ * all strictly newer than everything indexed become a small DELTA shard placed in front of the
+ * existing ones (candidate order is CreatedAt-descending); searches then run per shard and are
+ * merged exactly like a multi-GPU search (orr_search_shard + orr_merge_candidates).  Deletes,
+ * replaced chunk lists, older timestamps, a different embedding dimension or more than 8 shards
+ * trigger a full rebuild.  Counters for tests/metrics: */
+void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebuilds, int64_t *delta_builds);
 /* SearchAsync(query, topK) with the query embedding supplied by the caller (the
  * IEmbeddingClient result; qdim 0 = empty vector) and a frozen clock.  *out_json is
  * malloc'd; release it with orrh_free.  A blank query is ORR_EINVAL "Query is required." */

@@ -64,6 +64,8 @@ hip.orr_index_append.restype = C.c_int
 hip.orr_index_append.argtypes = [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]
 hip.orr_index_seal.restype = C.c_int
 hip.orr_index_seal.argtypes = [_vp]
+hip.orr_index_set_row_base.restype = C.c_int
+hip.orr_index_set_row_base.argtypes = [_vp, _i64]
 hip.orr_index_rows.restype = _i64
 hip.orr_index_rows.argtypes = [_vp]
 hip.orr_index_dim.restype = _i32
@@ -108,6 +110,8 @@ host.orrh_store_chunk_count.restype = _i64
 host.orrh_store_chunk_count.argtypes = [_vp]
 host.orrh_service_create.restype = _vp
 host.orrh_service_create.argtypes = [_vp, _i32, _i64]
+host.orrh_service_stats.restype = None
+host.orrh_service_stats.argtypes = [_vp, _vp, _vp, _vp]
 host.orrh_service_destroy.restype = None
 host.orrh_service_destroy.argtypes = [_vp]
 host.orrh_service_search_json.restype = C.c_int
@@ -135,13 +139,13 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
     "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
-    "orr_index_save", "orr_index_load",
+    "orr_index_save", "orr_index_load", "orr_index_set_row_base",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_service_create", "orrh_service_destroy",
-                         "orrh_service_search_json", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
+                         "orrh_service_search_json", "orrh_service_stats", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
                          "orrh_batcher_search", "orrh_batcher_stats"]
 
 

@@ -39,7 +39,17 @@ struct orrh_store {
     std::vector<std::string> doc_order;                 // enumeration order of _chunksByDocument
     std::map<std::string, Document> documents;
     std::map<std::string, std::vector<Chunk>> chunks_by_document;
-    uint64_t version = 0;
+    std::map<std::string, uint64_t> chunk_stamp;        // document -> version of its current chunk list
+    uint64_t version = 0;                               // any change
+    uint64_t chunks_version = 0;                        // changes the index has to follow
+};
+
+struct Shard {                       // one sealed orr_index and the chunks behind its row ids
+    orr_index *index = nullptr;
+    std::vector<Chunk> chunks;       // row id = id_base + position in this vector
+    int64_t id_base = 0;
+    int64_t min_created = 0, max_created = 0;
+    std::map<std::string, uint64_t> doc_stamps;
 };
 
 struct orrh_service {
@@ -47,10 +57,11 @@ struct orrh_service {
     int32_t device = 0;
     int64_t candidate_limit = 300;
     std::mutex mu;
-    orr_index *index = nullptr;
+    std::vector<Shard> shards;       // newest first = global candidate order
+    int32_t dim = 0;
     uint64_t built_version = ~0ull;
-    std::vector<const Chunk *> rows;                    // row id -> chunk
-    std::vector<Chunk> snapshot;
+    int64_t next_id = 0;
+    int64_t full_rebuilds = 0, delta_builds = 0;
 };
 
 namespace {
@@ -123,61 +134,178 @@ std::string iso_utc(int64_t ticks)
     return out;
 }
 
-// (Re)build the device index from the store: chunk lists in enumeration order, as
-// GetRecentChunksAsync flattens them (InMemoryIngestionStore.cs:59-60).
-int ensure_index(orrh_service *svc)
+void free_shards(orrh_service *svc)
 {
-    std::lock_guard<std::mutex> sl(svc->store->mu);
-    if (svc->index && svc->built_version == svc->store->version) return ORR_OK;
-    if (svc->index) { orr_index_destroy(svc->index); svc->index = nullptr; }
-    svc->snapshot.clear();
-    for (const auto &doc : svc->store->doc_order) {
-        auto it = svc->store->chunks_by_document.find(doc);
-        if (it == svc->store->chunks_by_document.end()) continue;
-        for (const auto &c : it->second) svc->snapshot.push_back(c);
-    }
-    int32_t dim = 0;
-    {   // index dimension = the most common non-empty embedding length
-        std::map<int32_t, int64_t> hist;
-        for (const auto &c : svc->snapshot) if (!c.embedding.empty()) hist[(int32_t)c.embedding.size()]++;
-        int64_t best = 0;
-        for (auto &kv : hist) if (kv.second > best) { best = kv.second; dim = kv.first; }
-    }
+    for (auto &sh : svc->shards)
+        if (sh.index) orr_index_destroy(sh.index);
+    svc->shards.clear();
+}
+
+// One sealed shard from chunks given in store enumeration order.
+int build_shard(orrh_service *svc, std::vector<Chunk> &&chunks, int32_t dim, Shard *out)
+{
+    Shard sh;
+    sh.chunks = std::move(chunks);
+    sh.id_base = svc->next_id;
+    svc->next_id += (int64_t)sh.chunks.size();
     orr_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.struct_size = (int32_t)sizeof(cfg);
     cfg.device = svc->device;
     cfg.dim = dim;
-    int r = orr_index_create(&cfg, &svc->index);
+    int r = orr_index_create(&cfg, &sh.index);
     if (r != ORR_OK) return fail(r, orr_last_error());
-    svc->rows.clear();
-    const size_t n = svc->snapshot.size();
+    const size_t n = sh.chunks.size();
+    sh.min_created = n ? sh.chunks[0].created_ticks : 0;
+    sh.max_created = sh.min_created;
     size_t i = 0;
     while (i < n) {                                   // runs of rows with / without a usable embedding
-        const bool has = dim > 0 && (int32_t)svc->snapshot[i].embedding.size() == dim;
+        const bool has = dim > 0 && (int32_t)sh.chunks[i].embedding.size() == dim;
         size_t e = i;
         std::vector<float> emb;
-        std::vector<int64_t> created;
+        std::vector<int64_t> created, ids;
         std::vector<uint64_t> off{0};
         std::string pool;
-        while (e < n && (dim > 0 && (int32_t)svc->snapshot[e].embedding.size() == dim) == has && e - i < 65536) {
-            const Chunk &c = svc->snapshot[e];
+        while (e < n && (dim > 0 && (int32_t)sh.chunks[e].embedding.size() == dim) == has && e - i < 65536) {
+            const Chunk &c = sh.chunks[e];
             if (has) emb.insert(emb.end(), c.embedding.begin(), c.embedding.end());
             created.push_back(c.created_ticks);
+            ids.push_back(sh.id_base + (int64_t)e);
+            sh.min_created = std::min(sh.min_created, c.created_ticks);
+            sh.max_created = std::max(sh.max_created, c.created_ticks);
             pool += lower(c.content);                 // Content.ToLowerInvariant(), :110 hoisted to ingest
             off.push_back(pool.size());
             ++e;
         }
-        r = orr_index_append(svc->index, (int64_t)(e - i), has ? dim : 0, has ? emb.data() : nullptr, created.data(),
-                             reinterpret_cast<const uint8_t *>(pool.data()), off.data(), nullptr);
-        if (r != ORR_OK) return fail(r, orr_last_error());
+        r = orr_index_append(sh.index, (int64_t)(e - i), has ? dim : 0, has ? emb.data() : nullptr, created.data(),
+                             reinterpret_cast<const uint8_t *>(pool.data()), off.data(), ids.data());
+        if (r != ORR_OK) { orr_index_destroy(sh.index); return fail(r, orr_last_error()); }
         i = e;
     }
-    for (const auto &c : svc->snapshot) svc->rows.push_back(&c);
-    r = orr_index_seal(svc->index);
-    if (r != ORR_OK) return fail(r, orr_last_error());
-    svc->built_version = svc->store->version;
+    r = orr_index_seal(sh.index);
+    if (r != ORR_OK) { orr_index_destroy(sh.index); return fail(r, orr_last_error()); }
+    for (const auto &c : sh.chunks) sh.doc_stamps[c.document_id] = 0;
+    *out = std::move(sh);
     return ORR_OK;
+}
+
+int32_t majority_dim(const std::vector<Chunk> &chunks)
+{
+    std::map<int32_t, int64_t> hist;
+    for (const auto &c : chunks) if (!c.embedding.empty()) hist[(int32_t)c.embedding.size()]++;
+    int32_t dim = 0;
+    int64_t best = 0;
+    for (auto &kv : hist) if (kv.second > best) { best = kv.second; dim = kv.first; }
+    return dim;
+}
+
+void assign_row_bases(orrh_service *svc)
+{
+    int64_t base = 0;
+    for (auto &sh : svc->shards) {                    // newest shard first
+        orr_index_set_row_base(sh.index, base);
+        base += (int64_t)sh.chunks.size();
+    }
+}
+
+// Bring the device shards up to date with the store (the :26 data source).  Chunk lists are
+// flattened in enumeration order, as GetRecentChunksAsync does (InMemoryIngestionStore.cs:59-60).
+int ensure_index(orrh_service *svc)
+{
+    std::lock_guard<std::mutex> sl(svc->store->mu);
+    orrh_store *st = svc->store;
+    if (!svc->shards.empty() && svc->built_version == st->chunks_version) return ORR_OK;
+
+    // what is indexed vs what the store holds now
+    std::map<std::string, uint64_t> indexed;
+    for (const auto &sh : svc->shards) for (const auto &kv : sh.doc_stamps) indexed[kv.first] = kv.second;
+    bool changed = false;
+    for (const auto &kv : indexed) {
+        auto it = st->chunk_stamp.find(kv.first);
+        if (it == st->chunk_stamp.end() || it->second != kv.second) { changed = true; break; }
+    }
+    std::vector<Chunk> added;
+    std::map<std::string, uint64_t> added_stamps;
+    if (!changed)
+        for (const auto &doc : st->doc_order) {
+            if (indexed.count(doc)) continue;
+            auto it = st->chunks_by_document.find(doc);
+            if (it == st->chunks_by_document.end()) continue;
+            for (const auto &c : it->second) added.push_back(c);
+            added_stamps[doc] = st->chunk_stamp[doc];
+        }
+    bool delta_ok = !changed && !svc->shards.empty() && svc->shards.size() < 8 && !added.empty();
+    if (delta_ok) {
+        int64_t newest = svc->shards[0].max_created;
+        for (const auto &sh : svc->shards) newest = std::max(newest, sh.max_created);
+        const int32_t d = majority_dim(added);
+        for (const auto &c : added) delta_ok = delta_ok && c.created_ticks > newest;      // strictly newer: ties keep enumeration order
+        delta_ok = delta_ok && (d == svc->dim || d == 0);
+    }
+    if (delta_ok) {
+        Shard sh;
+        int r = build_shard(svc, std::move(added), svc->dim, &sh);
+        if (r != ORR_OK) return r;
+        sh.doc_stamps = added_stamps;
+        svc->shards.insert(svc->shards.begin(), std::move(sh));
+        svc->delta_builds++;
+    } else if (changed || svc->shards.empty() || !added.empty()) {
+        free_shards(svc);
+        std::vector<Chunk> all;
+        std::map<std::string, uint64_t> stamps;
+        for (const auto &doc : st->doc_order) {
+            auto it = st->chunks_by_document.find(doc);
+            if (it == st->chunks_by_document.end()) continue;
+            for (const auto &c : it->second) all.push_back(c);
+            stamps[doc] = st->chunk_stamp[doc];
+        }
+        svc->dim = majority_dim(all);
+        Shard sh;
+        int r = build_shard(svc, std::move(all), svc->dim, &sh);
+        if (r != ORR_OK) return r;
+        sh.doc_stamps = stamps;
+        svc->shards.push_back(std::move(sh));
+        svc->full_rebuilds++;
+    }
+    assign_row_bases(svc);
+    svc->built_version = st->chunks_version;
+    return ORR_OK;
+}
+
+const Chunk *chunk_of(const orrh_service *svc, int64_t row_id)
+{
+    for (const auto &sh : svc->shards)
+        if (row_id >= sh.id_base && row_id < sh.id_base + (int64_t)sh.chunks.size()) return &sh.chunks[(size_t)(row_id - sh.id_base)];
+    return nullptr;
+}
+
+// RecallSearchService.cs:26-37 over one or several shards.
+int search_shards(orrh_service *svc, int32_t qdim, const float *qvec, const uint8_t *terms, const uint32_t *term_off,
+                  const uint32_t *qoff, int64_t now_ticks, int32_t topk, int64_t *rows, double *scores, int32_t *count)
+{
+    if (svc->shards.size() == 1) {
+        int r = orr_search_batch(svc->shards[0].index, 1, qdim, qdim > 0 ? qvec : nullptr, terms, term_off, qoff, now_ticks, topk,
+                                 svc->candidate_limit, rows, scores, count);
+        return r == ORR_OK ? ORR_OK : fail(r, orr_last_error());
+    }
+    const int32_t n_sh = (int32_t)svc->shards.size();
+    int64_t total = 0;
+    for (const auto &sh : svc->shards) total += (int64_t)sh.chunks.size();
+    int64_t kprime = std::min<int64_t>(std::max<int64_t>(total, 1), std::max<int64_t>(std::max(1, topk) + 22, 32));
+    for (;;) {
+        std::vector<orr_candidate> recs((size_t)n_sh * ((size_t)kprime + 1));
+        for (int32_t i = 0; i < n_sh; ++i) {
+            int r = orr_search_shard(svc->shards[i].index, 1, qdim, qdim > 0 ? qvec : nullptr, terms, term_off, qoff, now_ticks,
+                                     (int32_t)kprime, svc->candidate_limit, recs.data() + (size_t)i * (kprime + 1));
+            if (r != ORR_OK) return fail(r, orr_last_error());
+        }
+        int32_t unc = 0;
+        int r = orr_merge_candidates(n_sh, 1, (int32_t)kprime, recs.data(), svc->dim, qdim, qvec, qoff, now_ticks, topk, rows, scores,
+                                     count, &unc);
+        if (r != ORR_OK) return fail(r, orr_last_error());
+        if (unc == 0 || kprime >= total) return ORR_OK;
+        kprime = std::min<int64_t>(total, kprime * 4);
+    }
 }
 
 }  // namespace
@@ -222,6 +350,8 @@ int orrh_store_upsert_chunks(orrh_store *s, const char *document_id, int32_t n, 
     if (!s->chunks_by_document.count(document_id)) s->doc_order.push_back(document_id);
     s->chunks_by_document[document_id] = std::move(list);
     s->version++;
+    s->chunks_version++;
+    s->chunk_stamp[document_id] = s->chunks_version;
     return ORR_OK;
 }
 
@@ -230,8 +360,11 @@ int orrh_store_delete_document(orrh_store *s, const char *document_id)
     if (!s || !document_id) return fail(ORR_EINVAL, "orrh_store_delete_document: null argument");
     std::lock_guard<std::mutex> l(s->mu);
     s->documents.erase(document_id);
-    if (s->chunks_by_document.erase(document_id))
+    if (s->chunks_by_document.erase(document_id)) {
         s->doc_order.erase(std::remove(s->doc_order.begin(), s->doc_order.end(), std::string(document_id)), s->doc_order.end());
+        s->chunk_stamp.erase(document_id);
+        s->chunks_version++;
+    }
     s->version++;
     return ORR_OK;
 }
@@ -255,8 +388,17 @@ orrh_service *orrh_service_create(orrh_store *s, int32_t device, int64_t candida
 void orrh_service_destroy(orrh_service *svc)
 {
     if (!svc) return;
-    if (svc->index) orr_index_destroy(svc->index);
+    free_shards(svc);
     delete svc;
+}
+
+void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebuilds, int64_t *delta_builds)
+{
+    if (!svc) return;
+    std::lock_guard<std::mutex> l(svc->mu);
+    if (n_shards) *n_shards = (int32_t)svc->shards.size();
+    if (full_rebuilds) *full_rebuilds = svc->full_rebuilds;
+    if (delta_builds) *delta_builds = svc->delta_builds;
 }
 
 void orrh_free(void *p) { free(p); }
@@ -285,9 +427,9 @@ int orrh_service_search_json(orrh_service *svc, const char *query_utf8, const fl
     std::vector<int64_t> rows((size_t)k, -1);
     std::vector<double> scores((size_t)k, 0.0);
     int32_t count = 0;
-    r = orr_search_batch(svc->index, 1, qdim, qdim > 0 ? qvec : nullptr, terms.data(), term_off.data(), qoff, now_ticks,
-                         topk, svc->candidate_limit, rows.data(), scores.data(), &count);     // replaces :26-37
-    if (r != ORR_OK) return fail(r, orr_last_error());
+    r = search_shards(svc, qdim, qvec, terms.data(), term_off.data(), qoff, now_ticks, topk, rows.data(), scores.data(),
+                      &count);                                                                // replaces :26-37
+    if (r != ORR_OK) return r;
 
     std::string js = "{\"query\":";
     json_string(query, js);
@@ -295,7 +437,9 @@ int orrh_service_search_json(orrh_service *svc, const char *query_utf8, const fl
     {
         std::lock_guard<std::mutex> sl(svc->store->mu);
         for (int32_t i = 0; i < count; ++i) {
-            const Chunk &c = *svc->rows[(size_t)rows[i]];
+            const Chunk *cp = chunk_of(svc, rows[i]);
+            if (!cp) return fail(ORR_ECOMM, "search returned an unknown row id");
+            const Chunk &c = *cp;
             auto d = svc->store->documents.find(c.document_id);                               // :39,44
             const std::string file = d == svc->store->documents.end() ? "unknown" : d->second.file_name;   // :47
             std::string snip(4 * c.content.size() + 16, '\0');

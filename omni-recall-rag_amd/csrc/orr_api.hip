@@ -432,6 +432,14 @@ void orr_index_destroy(orr_index *idx)
     delete idx;
 }
 
+int orr_index_set_row_base(orr_index *idx, int64_t row_base)
+{
+    if (!idx || row_base < 0) return fail(ORR_EINVAL, "orr_index_set_row_base: bad argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->row_base = row_base;
+    return ORR_OK;
+}
+
 int64_t orr_index_rows(const orr_index *idx) { return idx ? idx->n_rows : 0; }
 int32_t orr_index_dim(const orr_index *idx) { return idx ? idx->dim : 0; }
 

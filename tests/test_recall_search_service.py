@@ -188,3 +188,59 @@ def test_chat_evidence_guard_consumer_sees_the_same_scores():
         assert ["%.4f" % s for s in got] == ["%.4f" % s for s in rounded]      # score={c.Score:F4}
         sut.close()
     store.close()
+
+
+@pytest.mark.gpu
+def test_uploads_after_the_first_build_become_delta_shards():
+    """newer documents are indexed as small delta shards in front of the existing ones
+    (no full rebuild); searches over several shards stay identical to the oracle over the whole store;
+    deletes and out-of-order timestamps fall back to a rebuild."""
+    S = _svc()
+    rng = np.random.default_rng(31)
+    store = S.InMemoryIngestionStore()
+    words = ["alpha", "beta", "gamma", "delta", "kubernetes", "azure"]
+    chunks_flat = []
+
+    def upload(doc, created, n_chunks=6):
+        store.UpsertDocument(S.CosmosDocumentRecord(doc, doc + ".md", created))
+        cs = [S.CosmosChunkRecord("%s:%04d" % (doc, i), doc, i, " ".join(rng.choice(words, 8)),
+                                  rng.standard_normal(16).astype(np.float32), created) for i in range(n_chunks)]
+        store.UpsertChunks(cs)
+        chunks_flat.extend(cs)
+
+    def check(sut, k=8):
+        cor = orc.OracleCorpus([c.Embedding for c in chunks_flat], [c.CreatedAtTicks for c in chunks_flat],
+                               [c.Content for c in chunks_flat])
+        for text in ("alpha kubernetes", "the gamma", "zzz"):
+            body = sut.Search(text, k)
+            rows, _, rounded = cor.search(qv, text, NOW, k, candidate_limit=sut_limit)
+            assert [(c["chunkId"], c["score"]) for c in body["citations"]] == \
+                   [(chunks_flat[r].Id, rd) for r, rd in zip(rows, rounded)]
+
+    qv = rng.standard_normal(16).astype(np.float32)
+    base_time = NOW - 100 * 864000000000
+    for d in range(30):
+        upload("old-%02d" % d, base_time + d * 1000)
+    for sut_limit in (300, 10**6):
+        sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=sut_limit, now_ticks=NOW)
+        check(sut)
+        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0}
+        t = base_time + 10**9 * (1 if sut_limit == 300 else 5)
+        for step in range(3):                                  # three rounds of newer uploads -> three delta shards
+            for j in range(2):
+                t += 7777
+                upload("new-%d-%d-%d" % (sut_limit, step, j), t)
+            check(sut)
+        st = sut.Stats()
+        assert st["shards"] == 4 and st["full_rebuilds"] == 1 and st["delta_builds"] == 3, st
+        upload("late-%d" % sut_limit, base_time - 5)            # older than what is indexed: order would break -> rebuild
+        check(sut)
+        assert sut.Stats()["shards"] == 1 and sut.Stats()["full_rebuilds"] == 2
+        store.DeleteDocument("old-03")                          # delete -> rebuild
+        chunks_flat[:] = [c for c in chunks_flat if c.DocumentId != "old-03"]
+        check(sut)
+        assert sut.Stats()["full_rebuilds"] == 3
+        sut.close()
+        # restore for the second pass
+        upload("old-03", base_time + 3 * 1000 + 1)
+    store.close()
