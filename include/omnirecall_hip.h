@@ -81,6 +81,7 @@ typedef struct orr_candidate {
 
 #define ORR_CAND_TRAILER   1
 #define ORR_CAND_DOT_EXACT 2   /* `dot` is already the reference-order fp64 sum */
+#define ORR_CAND_OVERFLOW  4   /* trailer only: the shard's candidate buffer overflowed; repeat unfused */
 
 /* Per-kernel timing collected with HIP events on the index's own stream. */
 typedef struct orr_kernel_stat {
@@ -184,6 +185,12 @@ int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_
  * (cfg->dim must be 0 or equal).  The loaded index is sealed. */
 int orr_index_save(orr_index *idx, const char *path);
 int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
+
+/* ---- tuning knobs ----------------------------------------------------------
+ * Integer options of one index; unknown names are ORR_EINVAL.
+ *   "fuse_epilogue"  0/1 (default 0): batches > 96 queries over >= 196,608 rows score and filter
+ *                    inside the GEMM epilogue instead of writing the dots to HBM. */
+int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
 
 /* ---- measurement ---------------------------------------------------------*/
 int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets the counters */

@@ -155,9 +155,10 @@ struct orr_index {
     std::vector<uint32_t> h_clen;      // host mirror of content lengths
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     bool sealed = false;
+    bool opt_fuse_epilogue = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -422,7 +423,8 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_vlen) (void)hipFree(idx->d_vlen);
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
-    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+    DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -781,6 +783,14 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
     return ORR_OK;
 }
 
+int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
+{
+    if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (strcmp(name, "fuse_epilogue") == 0) { idx->opt_fuse_epilogue = value != 0; return ORR_OK; }
+    return fail(ORR_EINVAL, "orr_index_set_option: unknown option %s", name);
+}
+
 int orr_index_set_profiling(orr_index *idx, int32_t enabled)
 {
     if (!idx) return fail(ORR_EINVAL, "null index");
@@ -819,6 +829,8 @@ struct BatchArgs {
     int64_t candidate_limit;
     bool force_exact = false;      // skip the MFMA candidate pass (escalation after a failed certificate)
     mutable bool used_mfma = false; // set by run_shard
+    bool no_fuse = false;          // keep the batched pass unfused (retry after a candidate-buffer overflow)
+    mutable bool used_fused = false;
 };
 
 int check_batch(const orr_index *idx, const BatchArgs &a, const char *fn)
@@ -884,6 +896,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
     const bool use_mfma = use_cos && !a.force_exact && B >= mfma_min_batch && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
     a.used_mfma = use_mfma;
+    a.used_fused = false;
     const bool direct_host = host_records && !use_mfma && rec_bytes <= (256u << 10);
     orr_candidate *d_cand = nullptr;
     if (direct_host) {
@@ -935,9 +948,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     float *d_dotf = nullptr;
     double approx_eps = 0.0;
     bool bf16_split = false;
+    int32_t fused_sample_seg = 0;      // > 0: fused epilogue behind a sampled prefix of that many segments
+    int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
-        ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
-        d_dotf = idx->ws_dotf.as<float>();
+        if (B <= 96 || getenv("ORR_GEMM_KIND")) {
+            ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
+            d_dotf = idx->ws_dotf.as<float>();
+        }
         if (B <= 96) {   // HBM-bound streaming form, 32 queries per launch
             for (int32_t b0 = 0; b0 < B; b0 += 32) {
                 const int32_t nq = std::min<int32_t>(32, B - b0);
@@ -950,9 +967,18 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
                 HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
             } else {
-                Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)n * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
+                // split bf16: queries split once; with enough rows the GEMM over everything behind a
+                // sampled prefix runs with the fused scoring epilogue (launched further down, once the
+                // floor keys exist) and only the prefix's dots go through HBM
                 ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
-                HIP_TRY(orr::launch_gemm_dot_bf16x3(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, idx->ws_qsplit.p, s));
+                HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+                const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
+                fused_sample_seg = (idx->opt_fuse_epilogue && !a.no_fuse && n_seg_all >= 48) ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16)) : 0;
+                dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
+                ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
+                d_dotf = idx->ws_dotf.as<float>();
+                Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
+                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, dotf_rows, idx->dim, d_dotf, dotf_rows, nullptr, s));
                 bf16_split = true;
             }
         }
@@ -1098,11 +1124,62 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             HIP_TRY(orr::launch_row_consts(idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->ws_rowc.as<double2>(), s));
             d_rowc = idx->ws_rowc.as<double2>();
         }
+        const int32_t n_seg32 = (int32_t)n_seg;
+        unsigned long long *d_tau = nullptr;
+        if (fused_sample_seg > 0) {
+            // ---- fused batched pass: prefix lists -> floor keys -> GEMM with the scoring epilogue ->
+            // survivors' buffers -> lists; the final merge reads prefix lists + buffer lists
+            a.used_fused = true;
+            constexpr uint32_t kCap = 4096;                                 // survivors kept per query
+            const int32_t buf_lists = (int32_t)(kCap / orr::kSelWidth);
+            const int32_t lists_total = fused_sample_seg + buf_lists;
+            ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)lists_total * orr::kSelWidth));
+            ORR_TRY(idx->ws_tau.reserve(sizeof(unsigned long long) * (size_t)B));
+            ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * (size_t)B));
+            ORR_TRY(idx->ws_fbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * kCap));
+            d_tau = idx->ws_tau.as<unsigned long long>();
+            {
+                Timed t(idx, "fuse_select", (double)B * (double)dotf_rows * 28.0);
+                HIP_TRY(orr::launch_fuse_select(nullptr, d_dotf, dotf_rows, idx->d_norm_b, idx->d_created, d_rowc, kw,
+                                                idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, dotf_rows, B, 0, fused_sample_seg,
+                                                nullptr, idx->ws_sel.as<orr::SelEntry>(), lists_total, s));
+            }
+            {
+                Timed t(idx, "select_floor", 0.0);
+                HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kprime, d_tau, s));
+            }
+            HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
+            ORR_TRY(idx->ws_fqf.reserve(sizeof(float2) * (size_t)B));
+            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float2>(), s));
+            orr::FusedEpilogue epi;
+            epi.any_bits = nullptr;
+            if (kw.bitmaps) {
+                ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * (size_t)B * (size_t)kw.words_per_term));
+                HIP_TRY(orr::launch_query_any_bits(kw, B, idx->ws_fany.as<uint32_t>(), s));
+                epi.any_bits = idx->ws_fany.as<uint32_t>();
+            }
+            epi.qf = idx->ws_fqf.as<float2>();
+            epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw; epi.tau = d_tau;
+            epi.cnt = idx->ws_fcnt.as<uint32_t>(); epi.buf = idx->ws_fbuf.as<orr::SelEntry>(); epi.cap = kCap;
+            {
+                Timed t(idx, "gemm_dot_bf16x3_fused", 4.0 * (double)(n - dotf_rows) * idx->dim + 4.0 * (double)B * idx->dim);
+                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, dotf_rows, n, idx->dim, nullptr, 0, &epi, s));
+            }
+            {
+                Timed t(idx, "buffer_to_lists", 0.0);
+                HIP_TRY(orr::launch_buffer_to_lists(epi.buf, epi.cnt, kCap, B, fused_sample_seg, lists_total,
+                                                    idx->ws_sel.as<orr::SelEntry>(), s));
+            }
+            {
+                Timed t(idx, "select_final", (double)B * (double)lists_total * orr::kSelWidth * sizeof(orr::SelEntry));
+                HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), lists_total, B, kprime, n, idx->row_base,
+                                                 nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                                 0, approx_eps, nullptr, epi.cnt, kCap, d_cand, s));
+            }
+        } else {
         // Large batches: scan a prefix first, take its k'-th best key per query as a floor, and let
         // the rest of the corpus skip every 64-row batch that cannot beat it.
-        const int32_t n_seg32 = (int32_t)n_seg;
         const int32_t sample_seg = (B >= 8 && n_seg32 >= 48) ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg32 / 16)) : 0;
-        unsigned long long *d_tau = nullptr;
         if (sample_seg > 0) {
             ORR_TRY(idx->ws_tau.reserve(sizeof(unsigned long long) * (size_t)B));
             d_tau = idx->ws_tau.as<unsigned long long>();
@@ -1110,7 +1187,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 Timed t(idx, "fuse_select", (double)B * (double)sample_seg * orr::kSelSegRows * 28.0);
                 HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, d_rowc, kw,
                                                 idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B, 0, sample_seg, nullptr,
-                                                idx->ws_sel.as<orr::SelEntry>(), s));
+                                                idx->ws_sel.as<orr::SelEntry>(), 0, s));
             }
             {
                 Timed t(idx, "select_floor", 0.0);
@@ -1121,13 +1198,14 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             Timed t(idx, "fuse_select", (double)B * (double)n * (8.0 * (use_cos ? 1 : 0) + 8.0 + 8.0));
             HIP_TRY(orr::launch_fuse_select(d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, d_rowc, kw,
                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, n, B, sample_seg, n_seg32 - sample_seg,
-                                            d_tau, idx->ws_sel.as<orr::SelEntry>(), s));
+                                            d_tau, idx->ws_sel.as<orr::SelEntry>(), 0, s));
         }
         {
             Timed t(idx, "select_final", (double)B * (double)n_seg * orr::kSelWidth * sizeof(orr::SelEntry));
             HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), (int32_t)n_seg, B, kprime, n, idx->row_base,
                                              d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                             use_mfma ? 0 : 1, approx_eps, nullptr, d_cand, s));
+                                             use_mfma ? 0 : 1, approx_eps, nullptr, nullptr, 0u, d_cand, s));
+        }
         }
         if (use_mfma) {   // K6: the survivors' dots again, now in the reference's own arithmetic
             Timed t(idx, "rescore_exact", (double)B * kprime * 4.0 * idx->dim);
@@ -1186,7 +1264,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
     std::vector<Ranked> ranked;
     double cutoff = -std::numeric_limits<double>::infinity();
     double eps = kCertifyEps;
-    bool any_cut = false;
+    bool any_cut = false, overflow = false;
     *err = ORR_OK;
     for (int32_t sidx = 0; sidx < n_shards; ++sidx) {
         const orr_candidate *rec = shard_recs[sidx];
@@ -1205,6 +1283,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
             ranked.push_back(r);
         }
         if (tr.dot > eps) eps = tr.dot;            // bound of the pass that produced this shard's records
+        if (tr.flags & ORR_CAND_OVERFLOW) overflow = true;
         if (tr.approx_score != -std::numeric_limits<double>::infinity()) {
             any_cut = true;
             // NaN cut-off: everything left out is NaN too (NaN sorts last), harmless
@@ -1222,7 +1301,9 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
         out_rows[i] = ranked[i].row_id;
         out_scores[i] = ranked[i].score;
     }
-    if (!any_cut) {
+    if (overflow) {
+        *certified = false;                       // some survivors were dropped: repeat unfused
+    } else if (!any_cut) {
         *certified = true;
     } else if (n_out < take) {
         *certified = false;                       // fewer results than asked while rows were cut
@@ -1266,7 +1347,7 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
                      int64_t candidate_limit, orr_candidate *out)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, false, false};
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
     ORR_TRY(check_batch(idx, a, "orr_search_shard"));
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
@@ -1294,7 +1375,7 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
                      int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_counts)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, false, false};
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
     ORR_TRY(check_batch(idx, a, "orr_search_batch"));
     if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_search_batch: output buffers are required");
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -1319,7 +1400,8 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
         ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, query_term_off, now_ticks,
                            topk, out_rows, out_scores, out_counts, &unc));
         if (unc == 0) return ORR_OK;
-        if (a.used_mfma) { a.force_exact = true; continue; }        // first retry: exact pass, same k'
+        if (a.used_fused && !a.no_fuse) { a.no_fuse = true; continue; }   // a buffer overflow or a tie at the cut: unfused pass
+        if (a.used_mfma) { a.force_exact = true; continue; }        // then the exact pass, same k'
         if (kprime >= n) return ORR_OK;
         kprime = std::min<int64_t>(n, kprime * 4);
     }

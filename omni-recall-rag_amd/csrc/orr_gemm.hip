@@ -7,6 +7,7 @@
 // reference's own arithmetic (RecallSearchService.cs:77-82) and the host certifies the
 // result against the cut-off (orr_api.hip).
 #include "orr_kernels.h"
+#include "orr_device.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -179,11 +180,17 @@ constexpr int kBfBM = 256;
 // ORR_BF16_TILE=256) halves the staging work per MFMA and measures the same 6.2 ms at B=256:
 // both sit at 42 % MfmaUtil, the ceiling of a two-barriers-per-K-step structure
 // (cdna_hip_programming.md, "the step-3 structure"); the next step is the 8-phase interleave.
-template <int NT, bool TWO_STAGE>
+// FUSED: instead of storing the dots, the epilogue scores every (query,row) of the tile
+// (fused_score_fast: cosine from the accumulator, keyword bits, per-row recency) and appends
+// the pairs that beat the query's floor key to that query's candidate buffer -- the scores
+// never leave the CU.  The floor is the k'-th best key of an already scanned prefix, so about
+// k' * rows / prefix entries per query get through.
+template <int NT, bool TWO_STAGE, bool FUSED>
 __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
-                                                                 int32_t B, const float *__restrict__ E, int64_t n_rows,
-                                                                 int32_t D, float *__restrict__ S, int64_t s_stride,
-                                                                 int32_t n_ntiles, int32_t n_mtiles)
+                                                                 int32_t B, const float *__restrict__ E, int64_t row_first,
+                                                                 int64_t n_rows, int32_t D, float *__restrict__ S,
+                                                                 int64_t s_stride, int32_t n_ntiles, int32_t n_mtiles,
+                                                                 FusedEpilogue epi)
 {
     constexpr int BN = 64 * NT;
     constexpr int NB = BN / 32;                         // float4 row pieces of the E tile per thread
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int mt = slot % n_mtiles, nt = (slot / n_mtiles) * 8 + xcd;
     if (nt >= n_ntiles) return;
-    const int64_t n0 = (int64_t)nt * BN;
+    const int64_t n0 = row_first + (int64_t)nt * BN;
     const int b0 = mt * kBfBM;
 
     // staging: A pieces are 16-byte (8 bf16) copies, 4 per image per thread; B pieces are float4
@@ -302,49 +309,187 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
             mfma_step();
         }
     }
+    if (!FUSED) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int64_t col = n0 + wn * 32 * NT + j * 32 + fr;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+                }
+            }
+    } else {
+        // fp32 pre-filter first: an upper bound of the score (full keyword credit) against the
+        // query's floor; only the few pairs that pass pay for the fp64 score, the keyword bits
+        // and the atomic append.
+        float rb[NT], rr[NT];
+        int64_t cols[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int64_t col = n0 + wn * 32 * NT + j * 32 + fr;
+            cols[j] = n0 + wn * 32 * NT + j * 32 + fr;                     // this lane's row of E
+            const bool ok = cols[j] < n_rows;
+            const double2 rc = ok ? epi.rowc[cols[j]] : make_double2(0.0, 0.0);
+            rb[j] = ok ? (float)rc.x : 0.f;
+            rr[j] = ok ? (float)rc.y : -__builtin_huge_valf();             // rows past the end never pass
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+                const int qi = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int qc_i = qi < B ? qi : B - 1;
+                const float2 qf = epi.qf[qc_i];                            // {0.7/sqrt(normA), floor - margin}
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    // full keyword credit only where some term of the query occurs in the row at all
+                    float credit = 0.f;
+                    if (epi.any_bits) {
+                        const uint32_t w = epi.any_bits[(int64_t)qc_i * epi.kw.words_per_term + (cols[j] >> 5)];
+                        credit = ((w >> (cols[j] & 31)) & 1u) ? 0.2f : 0.f;
+                    }
+                    const float upper = acc[i][j][e] * (qf.x * rb[j]) + rr[j] + credit;
+                    if (upper < qf.y || qi >= B) continue;                  // NaN falls through to the exact test
+                    const QueryConst qc = epi.qc[qi];
+                    const double2 rc = epi.rowc[cols[j]];
+                    const uint32_t m = qc.n_terms > 0 ? kw_matches(epi.kw, qi, (uint32_t)cols[j]) : 0u;
+                    const unsigned long long key = score_key(fused_score_fast((double)acc[i][j][e], rc.x, rc.y, m, qc));
+                    if (key > epi.tau[qi]) {
+                        const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
+                        if (slot < epi.cap) {
+                            SelEntry en;
+                            en.key = key; en.pos = (uint32_t)cols[j]; en.pad = 0;
+                            epi.buf[(int64_t)qi * epi.cap + slot] = en;
+                        }
+                    }
+                }
             }
-        }
+    }
 }
 
-template <int NT, bool TWO_STAGE>
-static hipError_t launch_bf16x3_variant(const __bf16 *q_hi, const __bf16 *q_lo, int32_t B, const float *E, int64_t n_rows,
-                                        int32_t D, float *S, int64_t s_stride, hipStream_t s)
+// any_bits[b][w] = OR over the query's terms of the term bitmaps: "some term of b occurs in the row".
+__global__ __launch_bounds__(256) void query_any_bits_kernel(KwView kw, int32_t B, uint32_t *__restrict__ out)
+{
+    const int64_t total = (int64_t)B * kw.words_per_term;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = id / kw.words_per_term, w = id - b * kw.words_per_term;
+        uint32_t acc = 0;
+        for (uint32_t i = kw.q_term_off[b]; i < kw.q_term_off[b + 1]; ++i)
+            acc |= kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + w];
+        out[id] = acc;
+    }
+}
+
+hipError_t launch_query_any_bits(KwView kw, int32_t B, uint32_t *out, hipStream_t s)
+{
+    if (B <= 0 || !kw.bitmaps) return hipSuccess;
+    int64_t blocks = ((int64_t)B * kw.words_per_term + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(query_any_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, kw, B, out);
+    return hipGetLastError();
+}
+
+// qf[b] = {0.7 / sqrt(normA) in fp32 (0 without cosine), floor score - margin}
+__global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryConst *__restrict__ qc,
+                                                                 const unsigned long long *__restrict__ tau, int32_t B,
+                                                                 float2 *__restrict__ qf)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const QueryConst c = qc[b];
+    float2 o;
+    o.x = c.use_cos ? (float)(c.inv_sqrt_na * 0.7) : 0.f;
+    if (tau[b] <= 1ull) {
+        o.y = -__builtin_huge_valf();                       // no floor (or a NaN floor): everything is tested exactly
+    } else {
+        const double floor_score = key_score(tau[b]);
+        // fp32 evaluation of cos*0.7 + rec*0.1 is off by < 2e-7 for scores of magnitude <= 1; 1e-5 margin,
+        // scaled up for larger magnitudes, and rounded down
+        const double margin = 1e-5 * (1.0 + fabs(floor_score));
+        o.y = __double2float_rd(floor_score - margin);
+    }
+    qf[b] = o;
+}
+
+hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float2 *qf, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fused_query_consts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, qc, tau, B, qf);
+    return hipGetLastError();
+}
+
+template <int NT, bool TWO_STAGE, bool FUSED>
+static hipError_t launch_bf16x3_variant(const __bf16 *q_hi, const __bf16 *q_lo, int32_t B, const float *E, int64_t row_first,
+                                        int64_t n_rows, int32_t D, float *S, int64_t s_stride, const FusedEpilogue &epi,
+                                        hipStream_t s)
 {
     constexpr int BN = 64 * NT;
-    const int64_t n_ntiles = (n_rows + BN - 1) / BN;
+    const int64_t n_ntiles = (n_rows - row_first + BN - 1) / BN;
+    if (n_ntiles <= 0) return hipSuccess;
     const int32_t n_mtiles = (B + kBfBM - 1) / kBfBM;
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = sizeof(__bf16) * (2 * kBfBM + 2 * BN) * kBfLd;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel<NT, TWO_STAGE>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gemm_dot_bf16x3_kernel<NT, TWO_STAGE>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B, E,
-                       n_rows, D, S, s_stride, (int32_t)n_ntiles, n_mtiles);
+    hipLaunchKernelGGL((gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B,
+                       E, row_first, n_rows, D, S, s_stride, (int32_t)n_ntiles, n_mtiles, epi);
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
-                                  int64_t s_stride, void *q_split_ws, hipStream_t s)
+hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_split_ws, hipStream_t s)
 {
-    if (B <= 0 || n_rows <= 0) return hipSuccess;
-    if (D % kGemmBK != 0) return hipErrorInvalidValue;
+    if (B <= 0 || D <= 0) return hipSuccess;
     __bf16 *q_hi = static_cast<__bf16 *>(q_split_ws), *q_lo = q_hi + (size_t)B * D;
     const int64_t nq = (int64_t)B * D;
     hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)std::min<int64_t>((nq / 4 + 255) / 256, 2048)), dim3(256), 0, s,
                        Q, nq, q_hi, q_lo);
+    return hipGetLastError();
+}
+
+// Rows [row_first, n_rows) of E against the pre-split queries.  epi == nullptr: dots to S;
+// otherwise the fused scoring/filter epilogue (nothing is written to S).
+hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
+                                  float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= row_first) return hipSuccess;
+    if (D % kGemmBK != 0) return hipErrorInvalidValue;
+    const __bf16 *q_hi = static_cast<const __bf16 *>(q_split_ws), *q_lo = q_hi + (size_t)B * D;
     static const int variant = [] { const char *e = getenv("ORR_BF16_TILE"); return e ? atoi(e) : 128; }();
-    if (variant == 128) return launch_bf16x3_variant<2, true>(q_hi, q_lo, B, E, n_rows, D, S, s_stride, s);
-    return launch_bf16x3_variant<4, false>(q_hi, q_lo, B, E, n_rows, D, S, s_stride, s);
+    const FusedEpilogue none{};
+    if (epi) return launch_bf16x3_variant<2, true, true>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, *epi, s);
+    if (variant == 256) return launch_bf16x3_variant<4, false, false>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
+    return launch_bf16x3_variant<2, true, false>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
+}
+
+// Candidate buffers of the fused pass -> sorted 64-entry lists appended behind the prefix's
+// lists (out_sel[b][seg_first + l]); empty lists where a query has fewer entries.
+__global__ __launch_bounds__(64) void buffer_to_lists_kernel(const SelEntry *__restrict__ buf, const uint32_t *__restrict__ cnt,
+                                                             uint32_t cap, int32_t seg_first, int32_t n_seg_total,
+                                                             SelEntry *__restrict__ out_sel)
+{
+    const int lane = threadIdx.x, b = blockIdx.x, l = blockIdx.y;
+    const uint32_t n = cnt[b] < cap ? cnt[b] : cap;
+    const uint32_t idx = (uint32_t)l * 64u + lane;
+    unsigned long long k = 0ull;
+    uint32_t p = 0xFFFFFFFFu;
+    if (idx < n) { const SelEntry e = buf[(int64_t)b * cap + idx]; k = e.key; p = e.pos; }
+    if ((uint32_t)l * 64u < n) wave_sort(k, p, lane);
+    SelEntry o;
+    o.key = k; o.pos = p; o.pad = 0;
+    out_sel[((int64_t)b * n_seg_total + seg_first + l) * kSelWidth + lane] = o;
+}
+
+hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint32_t cap, int32_t B, int32_t seg_first,
+                                  int32_t n_seg_total, SelEntry *out_sel, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(buffer_to_lists_kernel, dim3((unsigned)B, cap / 64), dim3(64), 0, s, buf, cnt, cap, seg_first, n_seg_total,
+                       out_sel);
+    return hipGetLastError();
 }
 
 // K2 v2: same tile and LDS image, but the image is DOUBLE-BUFFERED (139 KiB: one workgroup

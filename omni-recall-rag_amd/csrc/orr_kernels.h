@@ -98,7 +98,7 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
-                              SelEntry *out_sel, hipStream_t s);
+                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s);
 
 // K5b: merges the per-workgroup lists of each query and writes kprime candidate
 // records plus the trailer ([B][kprime+1], see orr_candidate).
@@ -109,17 +109,35 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
                                int64_t n_rows, int64_t row_base, const double *dot, const float *dotf,
                                int64_t dot_stride, const double *norm_b, const int64_t *created,
                                const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
-                               unsigned long long *tau_out, orr_candidate *out, hipStream_t s);
+                               unsigned long long *tau_out, const uint32_t *fused_cnt, uint32_t fused_cap,
+                               orr_candidate *out, hipStream_t s);
 
 // K2: S[b][r] ~= sum_k Q[b][k] * E[r][k] on the matrix cores (f32-input MFMA, fmaf chain in k
 // order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
 hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                                int64_t s_stride, hipStream_t s);
-// K2b: the same S from three bf16 MFMA products of on-the-fly hi/lo splits (see orr_gemm.hip for
-// the error bound); D % 64 == 0.
-// q_split_ws: device scratch of 4*B*D bytes for the queries' hi/lo halves.
-hipError_t launch_gemm_dot_bf16x3(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
-                                  int64_t s_stride, void *q_split_ws, hipStream_t s);
+// Fused epilogue of the batched candidate pass: score, compare with the query's floor key,
+// append survivors to the query's buffer (cap entries; cnt keeps counting past it).
+struct FusedEpilogue {
+    const double2 *rowc;               // per-row {1/sqrt(normB) or 0, recency*0.1}
+    const QueryConst *qc;
+    KwView kw;
+    const unsigned long long *tau;     // [B] floor keys
+    const float2 *qf;                  // [B] fp32 pre-filter constants (launch_fused_query_consts)
+    const uint32_t *any_bits;          // [B][words_per_term] "some term of the query occurs in the row", or null
+    uint32_t *cnt;                     // [B]
+    SelEntry *buf;                     // [B][cap]
+    uint32_t cap;
+};
+// K2b: S (or the fused epilogue) from three bf16 MFMA products of hi/lo splits (see orr_gemm.hip
+// for the error bound); D % 64 == 0.  q_split_ws: 4*B*D bytes filled by launch_split_queries.
+hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_split_ws, hipStream_t s);
+hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
+                                  float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s);
+hipError_t launch_query_any_bits(KwView kw, int32_t B, uint32_t *out, hipStream_t s);
+hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float2 *qf, hipStream_t s);
+hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint32_t cap, int32_t B, int32_t seg_first,
+                                  int32_t n_seg_total, SelEntry *out_sel, hipStream_t s);
 // K2s: the same for B <= 32 queries, streaming (HBM-bound) structure.
 hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
                             int64_t s_stride, hipStream_t s);

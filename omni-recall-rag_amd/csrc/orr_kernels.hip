@@ -12,62 +12,13 @@
 //
 // Built with -ffp-contract=off: nothing here may be fused or re-associated.
 #include "orr_kernels.h"
+#include "orr_device.h"
 
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
 
 namespace orr {
-
-// ---------------------------------------------------------------------------
-// score <-> sortable key.  Larger key = ranks earlier.  double.CompareTo puts
-// NaN below every number and treats -0 == +0.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long score_key(double s)
-{
-    if (s != s) return 1ull;
-    s = s + 0.0;                                   // -0 -> +0
-    unsigned long long u = (unsigned long long)__double_as_longlong(s);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-
-__device__ __forceinline__ double key_score(unsigned long long k)
-{
-    if (k <= 1ull) return __longlong_as_double(0x7FF8000000000000ll);
-    unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    return __longlong_as_double((long long)u);
-}
-
-// RecallSearchService.cs:59-67 with the per-chunk pieces already reduced.
-__device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t created, uint32_t matches,
-                                              const QueryConst &qc, int64_t now_ticks)
-{
-    double cosv = 0.0;
-    if (qc.use_cos) {
-        if (qc.norm_a <= 0.0 || norm_b <= 0.0)                               // :84-85
-            cosv = 0.0;
-        else
-            cosv = dot / (sqrt(qc.norm_a) * sqrt(norm_b));                   // :87
-    }
-    double kw = qc.n_terms > 0 ? (double)matches / (double)qc.n_terms : 0.0;  // :112
-    double total_days = (double)(now_ticks - created) / 864000000000.0;      // TimeSpan.TotalDays
-    double age_days = total_days > 0.0 ? total_days : 0.0;                   // :117
-    double rec = exp(-age_days / 30.0);                                      // :118
-    return (cosv * 0.7) + (kw * 0.2) + (rec * 0.1);                          // :66
-}
-
-// Selection-only form of the fused score for batches: per-row pieces (recency * 0.1 and
-// 1/sqrt(normB)) are computed once per batch (row_consts_kernel), per-query 1/sqrt(normA) on
-// the host.  It differs from fused_score by a few ulp (reciprocal-multiply instead of divide),
-// far inside the certificate's slack; the survivors are always re-scored exactly on the host.
-__device__ __forceinline__ double fused_score_fast(double dot, double inv_sqrt_nb, double rec01, uint32_t matches,
-                                                   const QueryConst &qc)
-{
-    double cosv = 0.0;
-    if (qc.use_cos) cosv = (inv_sqrt_nb == 0.0) ? 0.0 : dot * (qc.inv_sqrt_na * inv_sqrt_nb);   // normB <= 0 -> 0 (:84)
-    const double kw = (double)matches * qc.inv_n_terms;
-    return (cosv * 0.7) + (kw * 0.2) + rec01;
-}
 
 __global__ __launch_bounds__(256) void row_consts_kernel(const double *__restrict__ norm_b,
                                                          const int64_t *__restrict__ created, int64_t now_ticks,
@@ -92,19 +43,6 @@ hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(row_consts_kernel, dim3((unsigned)blocks), dim3(256), 0, s, norm_b, created, now_ticks, n_rows, out);
     return hipGetLastError();
-}
-
-// matches of RecallSearchService.cs:111 for (query b, row): how many of the query's
-// distinct terms have their bit set in the per-term row bitmaps (see expand_hits_kernel).
-__device__ __forceinline__ uint32_t kw_matches(const KwView &kw, int b, uint32_t row)
-{
-    uint32_t m = 0;
-    const uint32_t t0 = kw.q_term_off[b], t1 = kw.q_term_off[b + 1];
-    for (uint32_t i = t0; i < t1; ++i) {
-        const uint32_t word = kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + (row >> 5)];
-        m += (word >> (row & 31)) & 1u;
-    }
-    return m;
 }
 
 // ---------------------------------------------------------------------------
@@ -473,54 +411,6 @@ hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *count
 }
 
 // ---------------------------------------------------------------------------
-// Wave-resident top-64 list: lane i holds the i-th best entry (best first).
-// "better" = larger key, then smaller candidate position (stable order).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ bool better(unsigned long long ka, uint32_t pa, unsigned long long kb, uint32_t pb)
-{
-    return ka > kb || (ka == kb && pa < pb);
-}
-
-__device__ __forceinline__ void cmp_exchange(unsigned long long &k, uint32_t &p, int j, bool keep_better)
-{
-    const unsigned long long ok = __shfl_xor(k, j, 64);
-    const uint32_t op = __shfl_xor(p, j, 64);
-    const bool other_better = better(ok, op, k, p);
-    if (other_better == keep_better) { k = ok; p = op; }
-}
-
-// Full bitonic sort of one entry per lane, best first.
-__device__ __forceinline__ void wave_sort(unsigned long long &k, uint32_t &p, int lane)
-{
-#pragma unroll
-    for (int kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            const bool best_first = (lane & kk) == 0;
-            const bool lower = (lane & j) == 0;
-            cmp_exchange(k, p, j, best_first == lower);
-        }
-    }
-}
-
-// Sorts a bitonic sequence (one entry per lane) best first.
-__device__ __forceinline__ void wave_bitonic_merge(unsigned long long &k, uint32_t &p, int lane)
-{
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) cmp_exchange(k, p, j, (lane & j) == 0);
-}
-
-// list (sorted best first) <- best 64 of list U other (sorted best first).
-__device__ __forceinline__ void wave_merge_sorted(unsigned long long &k, uint32_t &p, unsigned long long ok,
-                                                  uint32_t op, int lane)
-{
-    const unsigned long long rk = __shfl(ok, 63 - lane, 64);
-    const uint32_t rp = __shfl(op, 63 - lane, 64);
-    if (better(rk, rp, k, p)) { k = rk; p = rp; }
-    wave_bitonic_merge(k, p, lane);
-}
-
-// ---------------------------------------------------------------------------
 // K4 + K5a  fused score and per-workgroup selection.  One workgroup scans
 // kSelSegRows rows of one query: each wave walks a quarter of them 64 at a time
 // (lane = row, coalesced 8-byte reads), skips batches that cannot enter its
@@ -612,10 +502,10 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
-                              SelEntry *out_sel, hipStream_t s)
+                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s)
 {
     if (n_rows <= 0 || B <= 0 || seg_count <= 0) return hipSuccess;
-    const int64_t n_seg = (n_rows + kSelSegRows - 1) / kSelSegRows;
+    const int64_t n_seg = n_seg_stride > 0 ? n_seg_stride : (n_rows + kSelSegRows - 1) / kSelSegRows;
     if (n_seg > 65535) return hipErrorInvalidValue;
     if (row_consts)
         hipLaunchKernelGGL(fuse_select_kernel<true>, dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
@@ -661,6 +551,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
                                                             const int64_t *__restrict__ row_ids, KwView kw,
                                                             int32_t dot_exact, double approx_eps,
                                                             unsigned long long *__restrict__ tau_out,
+                                                            const uint32_t *__restrict__ fused_cnt, uint32_t fused_cap,
                                                             orr_candidate *__restrict__ out)
 {
     __shared__ SelEntry lists[16][kSelWidth];
@@ -716,6 +607,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
             t.approx_score = (kept_all || n_valid == 0) ? -__builtin_huge_val() : key_score(worst_key);
             t.dot = approx_eps; t.norm_b = 0.0; t.created_ticks = 0;
             t.row_id = -1; t.order_key = n_rows; t.matches = n_valid; t.flags = ORR_CAND_TRAILER;
+            if (fused_cnt && fused_cnt[b] > fused_cap) t.flags |= ORR_CAND_OVERFLOW;
             o[kprime] = t;
         }
     }
@@ -725,12 +617,13 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
                                int64_t n_rows, int64_t row_base, const double *dot, const float *dotf,
                                int64_t dot_stride, const double *norm_b, const int64_t *created,
                                const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
-                               unsigned long long *tau_out, orr_candidate *out, hipStream_t s)
+                               unsigned long long *tau_out, const uint32_t *fused_cnt, uint32_t fused_cap,
+                               orr_candidate *out, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, n_seg, kprime, n_rows, row_base,
-                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, out);
+                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, fused_cnt, fused_cap, out);
     return hipGetLastError();
 }
 
@@ -742,7 +635,7 @@ hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, 
     const KwView nokw{nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, sample_seg, n_seg_total, kprime,
                        (int64_t)0, (int64_t)0, nullptr, nullptr, (int64_t)0, nullptr, nullptr, nullptr, nokw, 0, 0.0,
-                       tau_out, nullptr);
+                       tau_out, nullptr, 0u, nullptr);
     return hipGetLastError();
 }
 

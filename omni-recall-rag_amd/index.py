@@ -149,6 +149,9 @@ class RecallIndex:
                                        int(kprime), int(candidate_limit), _ptr(out)))
         return out
 
+    def set_option(self, name: str, value: int) -> None:
+        N.check(N.hip.orr_index_set_option(self._h, name.encode(), int(value)))
+
     def set_profiling(self, on: bool) -> None:
         N.check(N.hip.orr_index_set_profiling(self._h, 1 if on else 0))
 

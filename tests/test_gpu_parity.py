@@ -307,3 +307,41 @@ def test_shard_file_round_trip(tmp_path):
         P.RecallIndex.load(str(trunc))
     idx.close()
     re.close()
+
+
+def test_fused_batched_pass_matches_oracle():
+    """> 96 queries over >= 48 selection segments: the bf16x3 GEMM scores and filters in its epilogue
+    (scores never reach HBM behind the sampled prefix).  Same bit-exact results required."""
+    P = pkg()
+    rng = np.random.default_rng(77)
+    n, dim, B = 200_000, 64, 130
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "azure", "cosmos"])
+    contents = [" ".join(w) for w in words[rng.integers(0, len(words), (n, 5))]]
+    idx = P.RecallIndex(dim=dim)
+    step = 50_000
+    for r0 in range(0, n, step):
+        idx.append(emb[r0:r0 + step], created[r0:r0 + step], [c.encode() for c in contents[r0:r0 + step]])
+    idx.seal()
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[0] = emb[n - 7]                       # winners deep behind the prefix
+    qs[1] = emb[123_456] * 3.0
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    plain = idx.search(qs, terms, NOW, 10, candidate_limit=n)          # default: dots through HBM
+    idx.set_option("fuse_epilogue", 1)
+    with pytest.raises(P.OrrError):
+        idx.set_option("no_such_option", 1)
+    idx.set_profiling(True)
+    rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    stats = idx.kernel_stats()
+    assert "gemm_dot_bf16x3_fused" in stats and "buffer_to_lists" in stats, stats.keys()
+    assert all(np.array_equal(x, y) for x, y in zip(plain, (rows, scores, counts)))
+    corpus = orc.OracleCorpus(emb, created, contents)
+    assert rows[0, 0] == n - 7 and rows[1, 0] == 123_456
+    for b in list(range(0, 6)) + [64, 129]:
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+        assert list(rows[b, :counts[b]]) == list(orow), b
+        assert np.array_equal(scores[b, :counts[b]], osc), b
+    idx.close()
