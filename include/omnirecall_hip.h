@@ -188,7 +188,7 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
 
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
- *   "fuse_epilogue"  0/1 (default 0): batches > 96 queries over >= 196,608 rows score and filter
+ *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM. */
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
 

@@ -951,11 +951,11 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     int32_t fused_sample_seg = 0;      // > 0: fused epilogue behind a sampled prefix of that many segments
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
-        if (B <= 96 || getenv("ORR_GEMM_KIND")) {
+        if (B <= 64 || getenv("ORR_GEMM_KIND")) {
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
             d_dotf = idx->ws_dotf.as<float>();
         }
-        if (B <= 96) {   // HBM-bound streaming form, 32 queries per launch
+        if (B <= 64) {   // HBM-bound streaming form, 32 queries per launch (two launches at most)
             for (int32_t b0 = 0; b0 < B; b0 += 32) {
                 const int32_t nq = std::min<int32_t>(32, B - b0);
                 Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);

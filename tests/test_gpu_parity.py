@@ -228,7 +228,7 @@ def test_two_shards_on_one_gpu_equal_one_shard():
 
 @pytest.mark.parametrize("B,n,dim", [(5, 130, 64), (9, 700, 64), (33, 1000, 64), (40, 5000, 128), (130, 3000, 256), (256, 20000, 768)])
 def test_batched_mfma_candidate_pass_plus_exact_rescore_matches_oracle(B, n, dim):
-    """Batches >= 5 take K2 (f32 MFMA candidate pass: streaming form up to 96 queries, tiled GEMM
+    """Batches >= 5 take K2 (f32 MFMA candidate pass: streaming form up to 64 queries, tiled GEMM
     above) + K6 (exact re-score): the final ranking and scores must still be bit-identical."""
     P = pkg()
     rng = np.random.default_rng(B * 7 + n)
@@ -244,7 +244,7 @@ def test_batched_mfma_candidate_pass_plus_exact_rescore_matches_oracle(B, n, dim
     idx.set_profiling(True)
     rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=n)
     stats = idx.kernel_stats()
-    assert ("gemm_dot_bf16x3" if B > 96 else "gemv_mfma") in stats and "rescore_exact" in stats, stats.keys()
+    assert ("gemm_dot_bf16x3" if B > 64 else "gemv_mfma") in stats and "rescore_exact" in stats, stats.keys()
     check = range(B) if n <= 5000 else range(0, B, 16)
     for b in check:
         orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
@@ -344,4 +344,43 @@ def test_fused_batched_pass_matches_oracle():
         orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
         assert list(rows[b, :counts[b]]) == list(orow), b
         assert np.array_equal(scores[b, :counts[b]], osc), b
+    idx.close()
+
+
+def test_empty_and_degenerate_inputs():
+    """Empty corpus, rows with empty content, queries without terms or vectors, API misuse."""
+    P = pkg()
+    empty = P.RecallIndex(dim=8)
+    empty.seal()
+    rows, scores, counts = empty.search(np.ones((2, 8), np.float32), [[b"x"], []], NOW, 5, candidate_limit=300)
+    assert list(counts) == [0, 0] and (rows == -1).all()
+    with pytest.raises(P.OrrError) as ei:
+        empty.append(np.ones((1, 8), np.float32), [NOW], [b"late"])          # append after seal
+    assert ei.value.code == P.native.ORR_ESTATE
+    empty.close()
+
+    unsealed = P.RecallIndex(dim=4)
+    unsealed.append(np.ones((2, 4), np.float32), [NOW, NOW], [b"a", b"b"])
+    with pytest.raises(P.OrrError) as ei:
+        unsealed.search(np.ones((1, 4), np.float32), [[b"a"]], NOW, 1)
+    assert ei.value.code == P.native.ORR_ESTATE
+    with pytest.raises(P.OrrError) as ei:
+        unsealed.append(np.ones((1, 5), np.float32), [NOW], [b"c"])           # wrong dimension
+    assert ei.value.code == P.native.ORR_EDIM
+    unsealed.close()
+
+    c = {"emb": [np.array([1, 0, 0, 0], np.float32), None, np.array([0, 1, 0, 0], np.float32), np.zeros(4, np.float32)],
+         "created": np.array([NOW - DAY, NOW, NOW - 2 * DAY, NOW + DAY], np.int64), "contents": ["", "   ", "Alpha", ""], "dim": 4}
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    for qv, text in (([1, 0, 0, 0], "alpha"), (None, "alpha"), ([0, 0, 0, 0], "the"), ([1, 0, 0, 0], "zzz")):
+        for topk in (1, 3, 50):
+            assert_same_ranking(idx, corpus, c, qv, text, topk, 300)
+    # batch mixing a query with terms and one whose text is only stop words / symbols
+    qs = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)
+    texts = ["alpha", "the", "?!"]
+    rows, scores, counts = idx.search(qs, [P.text.query_terms(t) for t in texts], NOW, 4, candidate_limit=300)
+    for b in range(3):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 4, candidate_limit=300)
+        assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc)
     idx.close()
