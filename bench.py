@@ -44,10 +44,13 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=131072)
     ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    ap.add_argument("--no-terms", action="store_true", help="diagnostic: queries without keyword terms")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="orr_index_set_option on the shard before the run (e.g. two_stage=1)")
     return ap.parse_args()
 
 
-def build_shard(P, syn, torch, rank, rows, dim, n_total, dev):
+def build_shard(P, syn, torch, rank, rows, dim, n_total, dev, options=()):
     idx = P.RecallIndex(dim=dim, device=dev.index or 0, capacity_rows=rows, row_base=rank * rows)
     step = 32768
     for r0 in range(0, rows, step):
@@ -57,6 +60,9 @@ def build_shard(P, syn, torch, rank, rows, dim, n_total, dev):
         idx.append(syn.embeddings(g0, m, dim, dev), syn.created_ticks(g0, m, n_total, dev), pool, off)
     torch.cuda.synchronize()
     idx.seal()
+    for opt in options:
+        name, _, value = opt.partition("=")
+        idx.set_option(name, int(value or 1))
     return idx
 
 
@@ -111,7 +117,7 @@ def main():
 
     rows, dim, B_local, k = args.rows_per_gpu, args.dim, args.batch, args.topk
     n_total = rows * world
-    idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev)
+    idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
     # ORR_BENCH_FORCE_SHARDED=1 drives the sharded front-end (device tensors in, records out, host
     # merge) even on one GPU: a rehearsal of the N>1 code path without RCCL
     use_front = world > 1 or os.environ.get("ORR_BENCH_FORCE_SHARDED") == "1"
@@ -124,7 +130,7 @@ def main():
     for s in range(n_steps_total):
         b0 = (s * world + rank) * B_local
         q_steps.append(syn.query_vectors(b0, B_local, dim, n_total, dev))
-        term_steps.append([P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])
+        term_steps.append([[] if args.no_terms else P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])
     torch.cuda.synchronize()
 
     def step(s):
@@ -190,7 +196,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2: {rows} chunks x {dim}-d fp32 per GPU, {B_local} query per GPU per step, "
                                    f"top-k={k}, full hybrid (cosine+keyword+recency), candidate_limit=corpus",
-                       "corpus_rows": n_total, "queries_per_step": world * B_local,
+                       "corpus_rows": n_total, "queries_per_step": world * B_local, "options": args.set_option,
                        "parallelism": f"row-sharded x{world}, all-gather of per-shard top-k'" if world > 1 else "single GPU"},
             "row_scores_per_sec": queries * n_total / elapsed,
             "rank1_is_planted_row": ok,

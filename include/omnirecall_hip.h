@@ -82,6 +82,7 @@ typedef struct orr_candidate {
 #define ORR_CAND_TRAILER   1
 #define ORR_CAND_DOT_EXACT 2   /* `dot` is already the reference-order fp64 sum */
 #define ORR_CAND_OVERFLOW  4   /* trailer only: the shard's candidate buffer overflowed; repeat unfused */
+#define ORR_CAND_TWO_STAGE 8   /* trailer only: norm_b holds L; every row not offered has an exact score < L */
 
 /* Per-kernel timing collected with HIP events on the index's own stream. */
 typedef struct orr_kernel_stat {
@@ -189,7 +190,10 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
- *                    inside the GEMM epilogue instead of writing the dots to HBM. */
+ *                    inside the GEMM epilogue instead of writing the dots to HBM.
+ *   "two_stage"      0/1 (default 0): the same batches take ONE plain-bf16 product over all rows,
+ *                    keep every row that could reach the k-th best score of a sampled prefix
+ *                    (bound 2^-8 |q||e|), and re-score those exactly. */
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
 
 /* ---- measurement ---------------------------------------------------------*/

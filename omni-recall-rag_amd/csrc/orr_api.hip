@@ -156,9 +156,10 @@ struct orr_index {
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     bool sealed = false;
     bool opt_fuse_epilogue = false;
+    bool opt_two_stage = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -424,7 +425,7 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
-                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -788,6 +789,7 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
     if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
     std::lock_guard<std::mutex> lock(idx->mu);
     if (strcmp(name, "fuse_epilogue") == 0) { idx->opt_fuse_epilogue = value != 0; return ORR_OK; }
+    if (strcmp(name, "two_stage") == 0) { idx->opt_two_stage = value != 0; return ORR_OK; }
     return fail(ORR_EINVAL, "orr_index_set_option: unknown option %s", name);
 }
 
@@ -827,6 +829,7 @@ struct BatchArgs {
     const uint32_t *query_term_off;
     int64_t now_ticks;
     int64_t candidate_limit;
+    int32_t topk = 10;             // the caller's k (two-stage floor); kprime is passed separately
     bool force_exact = false;      // skip the MFMA candidate pass (escalation after a failed certificate)
     mutable bool used_mfma = false; // set by run_shard
     bool no_fuse = false;          // keep the batched pass unfused (retry after a candidate-buffer overflow)
@@ -949,6 +952,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     double approx_eps = 0.0;
     bool bf16_split = false;
     int32_t fused_sample_seg = 0;      // > 0: fused epilogue behind a sampled prefix of that many segments
+    bool two_stage = false;            // plain-bf16 first stage over all rows + exact second stage
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
         if (B <= 64 || getenv("ORR_GEMM_KIND")) {
@@ -973,20 +977,28 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
                 HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
                 const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-                fused_sample_seg = (idx->opt_fuse_epilogue && !a.no_fuse && n_seg_all >= 48) ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16)) : 0;
+                two_stage = idx->opt_two_stage && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
+                fused_sample_seg = ((idx->opt_fuse_epilogue || two_stage) && !a.no_fuse && n_seg_all >= 48)
+                                       ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16)) : 0;
                 dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
                 ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
                 d_dotf = idx->ws_dotf.as<float>();
                 Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
-                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, dotf_rows, idx->dim, d_dotf, dotf_rows, nullptr, s));
+                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, dotf_rows, idx->dim, d_dotf, dotf_rows, nullptr, 3, s));
                 bf16_split = true;
             }
         }
-        // f32 MFMA: |fmaf chain - reference sum| <= (D+2) 2^-24 sum|q_k e_k|; split bf16: see orr_gemm.hip.
-        // sum|q_k e_k| <= |q||e| (Cauchy-Schwarz) turns either into a bound on the cosine.
-        const double u24 = 5.9604644775390625e-08;
-        const double eps_cos = bf16_split ? 3.1 * 3.814697265625e-06 + (6.0 * idx->dim / 16.0 + 65.0) * u24
-                                          : (double)(idx->dim + 2) * u24;
+        // Error of the approximate dot against the reference sum, relative to sum|q_k e_k| (<= |q||e| by
+        // Cauchy-Schwarz, which turns it into a bound on the cosine).  The matrix cores' internal
+        // summation order and rounding mode are not documented, so every addition (and every fp32
+        // product) is charged one full unit in the last place, 2^-23, of a partial sum that never
+        // exceeds sum|terms|:
+        //   f32 MFMA    D products + D additions                      -> (2 D + 2) 2^-23
+        //   split bf16  3 D additions of exact products, plus the dropped lo*lo and the second-order
+        //               residuals of the split (u = 2^-8 per bf16 rounding) -> 3.1 u^2 + 3.06 D 2^-23
+        const double u23 = 1.1920928955078125e-07, u16 = 1.52587890625e-05;
+        const double eps_cos = bf16_split ? 3.1 * u16 + 3.06 * (double)idx->dim * u23
+                                          : (2.0 * (double)idx->dim + 2.0) * u23;
         approx_eps = 0.7 * 1.01 * eps_cos + 1e-12;
     } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
@@ -1130,7 +1142,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             // ---- fused batched pass: prefix lists -> floor keys -> GEMM with the scoring epilogue ->
             // survivors' buffers -> lists; the final merge reads prefix lists + buffer lists
             a.used_fused = true;
-            constexpr uint32_t kCap = 4096;                                 // survivors kept per query
+            constexpr uint32_t kCap = 8192;                                 // survivors kept per query
             const int32_t buf_lists = (int32_t)(kCap / orr::kSelWidth);
             const int32_t lists_total = fused_sample_seg + buf_lists;
             ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)lists_total * orr::kSelWidth));
@@ -1144,13 +1156,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                 idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, dotf_rows, B, 0, fused_sample_seg,
                                                 nullptr, idx->ws_sel.as<orr::SelEntry>(), lists_total, s));
             }
-            {
-                Timed t(idx, "select_floor", 0.0);
-                HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kprime, d_tau, s));
-            }
-            HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
             ORR_TRY(idx->ws_fqf.reserve(sizeof(float2) * (size_t)B));
-            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float2>(), s));
             orr::FusedEpilogue epi;
             epi.any_bits = nullptr;
             if (kw.bitmaps) {
@@ -1159,11 +1165,56 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 epi.any_bits = idx->ws_fany.as<uint32_t>();
             }
             epi.qf = idx->ws_fqf.as<float2>();
-            epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw; epi.tau = d_tau;
+            epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw;
             epi.cnt = idx->ws_fcnt.as<uint32_t>(); epi.buf = idx->ws_fbuf.as<orr::SelEntry>(); epi.cap = kCap;
+            HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
+            if (two_stage) {
+                // ---- two-stage: floor from the k-th best split-pass score of the prefix; ONE plain-bf16
+                // product over ALL rows keeps every row that can still reach it; those are re-scored
+                // exactly; the best k' of them become the records
+                const int32_t kth = std::max<int32_t>(1, a.topk);
+                // plain bf16: (1 + u)^2 - 1 per product with u = 2^-8, D additions charged 2^-23 each
+                const double eps1 = 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * 1.1920928955078125e-07) + 1e-12;
+                ORR_TRY(idx->ws_tsL.reserve(sizeof(double) * (size_t)B));
+                ORR_TRY(idx->ws_tskey.reserve(sizeof(unsigned long long) * (size_t)B));
+                {
+                    Timed t(idx, "select_floor", 0.0);
+                    HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kth, d_tau, s));
+                }
+                HIP_TRY(orr::launch_two_stage_floor(d_tau, B, approx_eps, eps1, idx->ws_tskey.as<unsigned long long>(),
+                                                    idx->ws_tsL.as<double>(), s));
+                HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
+                                                       idx->ws_fqf.as<float2>(), s));
+                epi.tau = idx->ws_tskey.as<unsigned long long>();
+                {
+                    Timed t(idx, "gemm_dot_bf16x1_fused", 4.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
+                    HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, n, idx->dim, nullptr, 0, &epi, 1, s));
+                }
+                {
+                    Timed t(idx, "rescore_buffer_exact", 0.0);
+                    HIP_TRY(orr::launch_rescore_buffer_exact(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, kw,
+                                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf, s));
+                }
+                {
+                    Timed t(idx, "buffer_to_lists", 0.0);
+                    HIP_TRY(orr::launch_buffer_to_lists(epi.buf, epi.cnt, kCap, B, 0, buf_lists, idx->ws_sel.as<orr::SelEntry>(), s));
+                }
+                {
+                    Timed t(idx, "select_final", (double)B * (double)buf_lists * orr::kSelWidth * sizeof(orr::SelEntry));
+                    HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), buf_lists, B, kprime, n, idx->row_base,
+                                                     nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                                     0, 0.0, nullptr, epi.cnt, kCap, idx->ws_tsL.as<double>(), d_cand, s));
+                }
+            } else {
+            {
+                Timed t(idx, "select_floor", 0.0);
+                HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kprime, d_tau, s));
+            }
+            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float2>(), s));
+            epi.tau = d_tau;
             {
                 Timed t(idx, "gemm_dot_bf16x3_fused", 4.0 * (double)(n - dotf_rows) * idx->dim + 4.0 * (double)B * idx->dim);
-                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, dotf_rows, n, idx->dim, nullptr, 0, &epi, s));
+                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, dotf_rows, n, idx->dim, nullptr, 0, &epi, 3, s));
             }
             {
                 Timed t(idx, "buffer_to_lists", 0.0);
@@ -1174,7 +1225,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 Timed t(idx, "select_final", (double)B * (double)lists_total * orr::kSelWidth * sizeof(orr::SelEntry));
                 HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), lists_total, B, kprime, n, idx->row_base,
                                                  nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                                 0, approx_eps, nullptr, epi.cnt, kCap, d_cand, s));
+                                                 0, approx_eps, nullptr, epi.cnt, kCap, nullptr, d_cand, s));
+            }
             }
         } else {
         // Large batches: scan a prefix first, take its k'-th best key per query as a floor, and let
@@ -1204,7 +1256,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             Timed t(idx, "select_final", (double)B * (double)n_seg * orr::kSelWidth * sizeof(orr::SelEntry));
             HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), (int32_t)n_seg, B, kprime, n, idx->row_base,
                                              d_dot, d_dotf, n, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                             use_mfma ? 0 : 1, approx_eps, nullptr, nullptr, 0u, d_cand, s));
+                                             use_mfma ? 0 : 1, approx_eps, nullptr, nullptr, 0u, nullptr, d_cand, s));
         }
         }
         if (use_mfma) {   // K6: the survivors' dots again, now in the reference's own arithmetic
@@ -1265,6 +1317,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
     double cutoff = -std::numeric_limits<double>::infinity();
     double eps = kCertifyEps;
     bool any_cut = false, overflow = false;
+    double need_score = -std::numeric_limits<double>::infinity();   // two-stage: rows never offered score below this
     *err = ORR_OK;
     for (int32_t sidx = 0; sidx < n_shards; ++sidx) {
         const orr_candidate *rec = shard_recs[sidx];
@@ -1284,6 +1337,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
         }
         if (tr.dot > eps) eps = tr.dot;            // bound of the pass that produced this shard's records
         if (tr.flags & ORR_CAND_OVERFLOW) overflow = true;
+        if ((tr.flags & ORR_CAND_TWO_STAGE) && tr.norm_b > need_score) need_score = tr.norm_b;
         if (tr.approx_score != -std::numeric_limits<double>::infinity()) {
             any_cut = true;
             // NaN cut-off: everything left out is NaN too (NaN sorts last), harmless
@@ -1301,15 +1355,19 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
         out_rows[i] = ranked[i].row_id;
         out_scores[i] = ranked[i].score;
     }
+    const bool lower_bounded = need_score != -std::numeric_limits<double>::infinity();
     if (overflow) {
         *certified = false;                       // some survivors were dropped: repeat unfused
-    } else if (!any_cut) {
+    } else if (!any_cut && !lower_bounded) {
         *certified = true;
     } else if (n_out < take) {
         *certified = false;                       // fewer results than asked while rows were cut
     } else {
         const double sk = ranked[n_out - 1].score;
-        *certified = sk > cutoff + eps;           // false for NaN
+        *certified = !any_cut || sk > cutoff + eps;           // false for NaN
+        // two-stage: rows that were never offered score below need_score, and the construction makes
+        // S_k >= need_score; a violated bound must not pass silently
+        if (*certified && lower_bounded) *certified = sk >= need_score - 1e-12;
     }
     return n_out;
 }
@@ -1347,7 +1405,7 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
                      int64_t candidate_limit, orr_candidate *out)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, kprime};
     ORR_TRY(check_batch(idx, a, "orr_search_shard"));
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
@@ -1375,7 +1433,7 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
                      int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_counts)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit};
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, topk};
     ORR_TRY(check_batch(idx, a, "orr_search_batch"));
     if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_search_batch: output buffers are required");
     std::lock_guard<std::mutex> lock(idx->mu);

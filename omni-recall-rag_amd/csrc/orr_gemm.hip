@@ -1,8 +1,9 @@
 // orr_gemm.hip -- batched candidate pass (K2) and exact re-score of the survivors (K6).
 //
 // K2: approximate dots S[b][r] = sum_k Q[b][k] * E[r][k] for a whole batch on the matrix
-// cores with the f32-input MFMA v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain, so
-// |S - reference dot| <= (D+2) * 2^-24 * sum|q_k e_k|).  It only has to be good enough to
+// cores with the f32-input MFMA v_mfma_f32_32x32x2_f32 (D products and D additions in fp32,
+// each charged one full ulp: |S - reference dot| <= (2D+2) * 2^-23 * sum|q_k e_k|; the cores'
+// internal rounding is not documented, see orr_api.hip).  It only has to be good enough to
 // pick k' >= k candidates per query; K6 then recomputes the survivors' dots in the
 // reference's own arithmetic (RecallSearchService.cs:77-82) and the host certifies the
 // result against the cut-off (orr_api.hip).
@@ -127,9 +128,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
 // hi = bf16(x) and lo = bf16(x - hi); the dot is accumulated from the three
 // products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA
 // rate per instruction, 3 instructions -> 5.3x), reading the fp32 master copy
-// once.  bf16 x bf16 products are exact in the fp32 accumulator, so
-//   |S - sum q_k e_k| <= [ 3.1 * 2^-18  (dropped lo*lo and second-order residuals)
-//                         + (6 D / 16 + 64) * 2^-24 (fp32 accumulation, doubled) ] * sum|q_k e_k|
+// once.  bf16 x bf16 products are exact in the fp32 accumulator; with u = 2^-8 the unit roundoff
+// of one bf16 rounding,
+//   |S - sum q_k e_k| <= [ 3.1 u^2        (dropped lo*lo and the second-order residuals of the split)
+//                         + 3.06 D 2^-23  (3 D fp32 additions, one full ulp each: the matrix core's
+//                                          internal order and rounding are not documented) ] * sum|q_k e_k|
 // which is the epsilon the certificate is given (orr_api.hip).
 //
 // LDS: hi and lo images of both operand tiles, [rows][64 k] bf16 with a 144-byte row
@@ -158,6 +161,13 @@ __device__ __forceinline__ void split_write(__bf16 *hi_img, __bf16 *lo_img, int 
 // Queries are split once per batch (split_queries_kernel); the row tile is split by the
 // workgroup that stages it.  Tile: 256 queries x 128 rows x 64 k, 8 waves as 4 x 2, each a
 // 64 x 64 sub-tile, so a row piece is converted once per 256 queries.
+__device__ __forceinline__ void hi_write(__bf16 *hi_img, int r, int c4, const float4 &v)
+{
+    bf16x4 h;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4 *>(hi_img + r * kBfLd + 4 * c4) = h;
+}
+
 __global__ __launch_bounds__(256) void split_queries_kernel(const float *__restrict__ Q, int64_t n,
                                                             __bf16 *__restrict__ q_hi, __bf16 *__restrict__ q_lo)
 {
@@ -185,7 +195,10 @@ constexpr int kBfBM = 256;
 // the pairs that beat the query's floor key to that query's candidate buffer -- the scores
 // never leave the CU.  The floor is the k'-th best key of an already scanned prefix, so about
 // k' * rows / prefix entries per query get through.
-template <int NT, bool TWO_STAGE, bool FUSED>
+// PROD = 3: hi*hi + hi*lo + lo*hi (the split pass).  PROD = 1: hi*hi only -- a plain bf16 pass
+// with |S - sum q_k e_k| <= [2^-7 (1 + 2^-9) + 1.02 D 2^-23] sum|q_k e_k|, a third of the
+// matrix work and half of the staging; only used as the wide first stage of the two-stage pass.
+template <int NT, bool TWO_STAGE, bool FUSED, int PROD>
 __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *__restrict__ Qh, const __bf16 *__restrict__ Ql,
                                                                  int32_t B, const float *__restrict__ E, int64_t row_first,
                                                                  int64_t n_rows, int32_t D, float *__restrict__ S,
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
     // A_hi, A_lo: [256][72] bf16; B_hi, B_lo: [BN][72] bf16
     extern __shared__ __attribute__((aligned(16))) __bf16 img[];
     __bf16 *a_hi = img, *a_lo = img + kBfBM * kBfLd, *b_hi = img + 2 * kBfBM * kBfLd, *b_lo = b_hi + BN * kBfLd;
+    if (PROD == 1) { b_hi = img + kBfBM * kBfLd; a_lo = nullptr; b_lo = nullptr; }     // hi images only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware order: ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
             const int r = it * 64 + la_r;
             const int qr = (b0 + r < B) ? b0 + r : B - 1;
             st.ah[it] = *reinterpret_cast<const bf16x8 *>(Qh + (int64_t)qr * D + k0 + la_c * 8);
-            st.al[it] = *reinterpret_cast<const bf16x8 *>(Ql + (int64_t)qr * D + k0 + la_c * 8);
+            if (PROD == 3) st.al[it] = *reinterpret_cast<const bf16x8 *>(Ql + (int64_t)qr * D + k0 + la_c * 8);
         }
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
@@ -231,10 +245,13 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
         for (int it = 0; it < 4; ++it) {
             const int r = it * 64 + la_r;
             *reinterpret_cast<bf16x8 *>(a_hi + r * kBfLd + la_c * 8) = st.ah[it];
-            *reinterpret_cast<bf16x8 *>(a_lo + r * kBfLd + la_c * 8) = st.al[it];
+            if (PROD == 3) *reinterpret_cast<bf16x8 *>(a_lo + r * kBfLd + la_c * 8) = st.al[it];
         }
 #pragma unroll
-        for (int it = 0; it < NB; ++it) split_write(b_hi, b_lo, it * 32 + lb_r, lb_c, st.b[it]);
+        for (int it = 0; it < NB; ++it) {
+            if (PROD == 3) split_write(b_hi, b_lo, it * 32 + lb_r, lb_c, st.b[it]);
+            else hi_write(b_hi, it * 32 + lb_r, lb_c, st.b[it]);
+        }
     };
     f32x16 acc[2][NT];
 #pragma unroll
@@ -255,25 +272,27 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 ah[i] = *reinterpret_cast<const bf16x8 *>(a_hi + a_off + i * 32 * kBfLd + ks * 16);
-                al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + a_off + i * 32 * kBfLd + ks * 16);
+                if (PROD == 3) al[i] = *reinterpret_cast<const bf16x8 *>(a_lo + a_off + i * 32 * kBfLd + ks * 16);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8 *>(b_hi + b_off + j * 32 * kBfLd + ks * 16);
-                bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + b_off + j * 32 * kBfLd + ks * 16);
+                if (PROD == 3) bl[j] = *reinterpret_cast<const bf16x8 *>(b_lo + b_off + j * 32 * kBfLd + ks * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            if (PROD == 3) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -420,7 +439,7 @@ hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long l
     return hipGetLastError();
 }
 
-template <int NT, bool TWO_STAGE, bool FUSED>
+template <int NT, bool TWO_STAGE, bool FUSED, int PROD>
 static hipError_t launch_bf16x3_variant(const __bf16 *q_hi, const __bf16 *q_lo, int32_t B, const float *E, int64_t row_first,
                                         int64_t n_rows, int32_t D, float *S, int64_t s_stride, const FusedEpilogue &epi,
                                         hipStream_t s)
@@ -431,11 +450,11 @@ static hipError_t launch_bf16x3_variant(const __bf16 *q_hi, const __bf16 *q_lo, 
     const int32_t n_mtiles = (B + kBfBM - 1) / kBfBM;
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    constexpr size_t lds_bytes = sizeof(__bf16) * (2 * kBfBM + 2 * BN) * kBfLd;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED>),
+    constexpr size_t lds_bytes = sizeof(__bf16) * (PROD == 3 ? 2 : 1) * (kBfBM + BN) * kBfLd;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED, PROD>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B,
+    hipLaunchKernelGGL((gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED, PROD>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B,
                        E, row_first, n_rows, D, S, s_stride, (int32_t)n_ntiles, n_mtiles, epi);
     return hipGetLastError();
 }
@@ -453,16 +472,133 @@ hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_sp
 // Rows [row_first, n_rows) of E against the pre-split queries.  epi == nullptr: dots to S;
 // otherwise the fused scoring/filter epilogue (nothing is written to S).
 hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
-                                  float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s)
+                                  float *S, int64_t s_stride, const FusedEpilogue *epi, int32_t products, hipStream_t s)
 {
     if (B <= 0 || n_rows <= row_first) return hipSuccess;
     if (D % kGemmBK != 0) return hipErrorInvalidValue;
     const __bf16 *q_hi = static_cast<const __bf16 *>(q_split_ws), *q_lo = q_hi + (size_t)B * D;
     static const int variant = [] { const char *e = getenv("ORR_BF16_TILE"); return e ? atoi(e) : 128; }();
     const FusedEpilogue none{};
-    if (epi) return launch_bf16x3_variant<2, true, true>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, *epi, s);
-    if (variant == 256) return launch_bf16x3_variant<4, false, false>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
-    return launch_bf16x3_variant<2, true, false>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
+    if (epi && products == 1) return launch_bf16x3_variant<2, true, true, 1>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, *epi, s);
+    if (epi) return launch_bf16x3_variant<2, true, true, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, *epi, s);
+    if (variant == 256) return launch_bf16x3_variant<4, false, false, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
+    return launch_bf16x3_variant<2, true, false, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
+}
+
+// Two-stage pass, floor: with s_k = the k-th best split-pass score of the sampled prefix,
+//   L = s_k - eps3           a lower bound of the exact k-th best score of the prefix, hence of the corpus
+//   F = L - eps1 - margin    a row whose plain-bf16 score is below F has an exact score below L
+// floor_key[b] = key(F) - 1 so that "key > floor_key" means "score >= F".
+__global__ __launch_bounds__(256) void two_stage_floor_kernel(const unsigned long long *__restrict__ tau_k, int32_t B,
+                                                              double eps3, double eps1,
+                                                              unsigned long long *__restrict__ floor_key,
+                                                              double *__restrict__ L_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (tau_k[b] <= 1ull) {                 // fewer than k rows in the prefix, or a NaN: keep everything (-> overflow -> retry)
+        floor_key[b] = 0ull;
+        L_out[b] = -__builtin_huge_val();
+        return;
+    }
+    const double sk = key_score(tau_k[b]);
+    const double L = sk - eps3;
+    const double F = L - eps1 - 1e-9 * (1.0 + fabs(sk));
+    const unsigned long long fk = score_key(F);
+    floor_key[b] = fk > 2ull ? fk - 1ull : 0ull;
+    L_out[b] = L;
+}
+
+hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
+                                  unsigned long long *floor_key, double *L_out, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(two_stage_floor_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, tau_k, B, eps3, eps1, floor_key, L_out);
+    return hipGetLastError();
+}
+
+// Two-stage pass, second stage: every buffered (query,row) pair gets its score again from the
+// reference-order fp64 dot (same wave-private swizzled tile walk as K6) and the exact fused
+// formula; the entry's key is overwritten with it.  One wave per 64 buffer entries of a query.
+__global__ __launch_bounds__(64) void rescore_buffer_exact_kernel(const float *__restrict__ E, int32_t D,
+                                                                  const float *__restrict__ Q,
+                                                                  const double *__restrict__ norm_b,
+                                                                  const int64_t *__restrict__ created, KwView kw,
+                                                                  const QueryConst *__restrict__ qcs, int64_t now_ticks,
+                                                                  const uint32_t *__restrict__ cnt, uint32_t cap,
+                                                                  SelEntry *__restrict__ buf)
+{
+    __shared__ __attribute__((aligned(16))) float tile[64 * 64];
+    __shared__ int64_t rows[64];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const uint32_t n = cnt[b] < cap ? cnt[b] : cap;
+    const uint32_t first = blockIdx.y * 64u;
+    if (first >= n) return;
+    SelEntry *mine = buf + (int64_t)b * cap + first;
+    const bool live = first + lane < n;
+    const int64_t my_row = live ? (int64_t)mine[lane].pos : -1;
+    rows[lane] = my_row;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ld_row = lane >> 4, ld_ch = lane & 15;
+    const float *q = Q + (int64_t)b * D;
+    double acc = 0.0;
+    float4 stage[16];
+    auto load_stage = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int64_t row = rows[it * 4 + ld_row];
+            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0) stage[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
+        }
+    };
+    load_stage(0);
+    for (int c0 = 0; c0 < D; c0 += 64) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + ld_row;
+            *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
+        }
+        if (c0 + 64 < D) load_stage(c0 + 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 e = *reinterpret_cast<const float4 *>(tile + lane * 64 + ((j ^ (lane & 15)) << 2));
+            const float *qp = q + c0 + j * 4;
+            float p0 = qp[0] * e.x;
+            acc += (double)p0;
+            float p1 = qp[1] * e.y;
+            acc += (double)p1;
+            float p2 = qp[2] * e.z;
+            acc += (double)p2;
+            float p3 = qp[3] * e.w;
+            acc += (double)p3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (live) {
+        const QueryConst qc = qcs[b];
+        const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
+        QueryConst exact = qc;
+        exact.use_cos = 1;                                   // this path only runs with cosine; guards are inside fused_score
+        mine[lane].key = score_key(fused_score(acc, norm_b[my_row], created[my_row], m, exact, now_ticks));
+    }
+}
+
+hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
+                                       const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
+                                       const uint32_t *cnt, uint32_t cap, SelEntry *buf, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    if (D % 64 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rescore_buffer_exact_kernel, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
+                       now_ticks, cnt, cap, buf);
+    return hipGetLastError();
 }
 
 // Candidate buffers of the fused pass -> sorted 64-entry lists appended behind the prefix's

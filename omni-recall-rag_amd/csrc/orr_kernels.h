@@ -110,7 +110,7 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
                                int64_t dot_stride, const double *norm_b, const int64_t *created,
                                const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
                                unsigned long long *tau_out, const uint32_t *fused_cnt, uint32_t fused_cap,
-                               orr_candidate *out, hipStream_t s);
+                               const double *two_stage_L, orr_candidate *out, hipStream_t s);
 
 // K2: S[b][r] ~= sum_k Q[b][k] * E[r][k] on the matrix cores (f32-input MFMA, fmaf chain in k
 // order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
@@ -133,9 +133,15 @@ struct FusedEpilogue {
 // for the error bound); D % 64 == 0.  q_split_ws: 4*B*D bytes filled by launch_split_queries.
 hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_split_ws, hipStream_t s);
 hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
-                                  float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s);
+                                  float *S, int64_t s_stride, const FusedEpilogue *epi, int32_t products, hipStream_t s);
 hipError_t launch_query_any_bits(KwView kw, int32_t B, uint32_t *out, hipStream_t s);
 hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float2 *qf, hipStream_t s);
+// Two-stage pass helpers (orr_gemm.hip).
+hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
+                                  unsigned long long *floor_key, double *L_out, hipStream_t s);
+hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
+                                       const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
+                                       const uint32_t *cnt, uint32_t cap, SelEntry *buf, hipStream_t s);
 hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint32_t cap, int32_t B, int32_t seg_first,
                                   int32_t n_seg_total, SelEntry *out_sel, hipStream_t s);
 // K2s: the same for B <= 32 queries, streaming (HBM-bound) structure.

@@ -552,6 +552,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
                                                             int32_t dot_exact, double approx_eps,
                                                             unsigned long long *__restrict__ tau_out,
                                                             const uint32_t *__restrict__ fused_cnt, uint32_t fused_cap,
+                                                            const double *__restrict__ two_stage_L,
                                                             orr_candidate *__restrict__ out)
 {
     __shared__ SelEntry lists[16][kSelWidth];
@@ -603,11 +604,13 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
         const unsigned long long worst_key = __shfl(k, (n_valid > 0 ? n_valid - 1 : 0), 64);
         if (lane == 0) {
             orr_candidate t;
-            const bool kept_all = n_rows <= (int64_t)kprime;
+            // two-stage: every buffered row became a record -> the only rows left out are below L
+            const bool kept_all = n_rows <= (int64_t)kprime || (two_stage_L && fused_cnt && fused_cnt[b] <= (uint32_t)kprime);
             t.approx_score = (kept_all || n_valid == 0) ? -__builtin_huge_val() : key_score(worst_key);
             t.dot = approx_eps; t.norm_b = 0.0; t.created_ticks = 0;
             t.row_id = -1; t.order_key = n_rows; t.matches = n_valid; t.flags = ORR_CAND_TRAILER;
             if (fused_cnt && fused_cnt[b] > fused_cap) t.flags |= ORR_CAND_OVERFLOW;
+            if (two_stage_L) { t.norm_b = two_stage_L[b]; t.flags |= ORR_CAND_TWO_STAGE; }
             o[kprime] = t;
         }
     }
@@ -618,12 +621,12 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
                                int64_t dot_stride, const double *norm_b, const int64_t *created,
                                const int64_t *row_ids, KwView kw, int32_t dot_exact, double approx_eps,
                                unsigned long long *tau_out, const uint32_t *fused_cnt, uint32_t fused_cap,
-                               orr_candidate *out, hipStream_t s)
+                               const double *two_stage_L, orr_candidate *out, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, n_seg, kprime, n_rows, row_base,
-                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, fused_cnt, fused_cap, out);
+                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, fused_cnt, fused_cap, two_stage_L, out);
     return hipGetLastError();
 }
 
@@ -635,7 +638,7 @@ hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, 
     const KwView nokw{nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, sample_seg, n_seg_total, kprime,
                        (int64_t)0, (int64_t)0, nullptr, nullptr, (int64_t)0, nullptr, nullptr, nullptr, nokw, 0, 0.0,
-                       tau_out, nullptr, 0u, nullptr);
+                       tau_out, nullptr, 0u, nullptr, nullptr);
     return hipGetLastError();
 }
 

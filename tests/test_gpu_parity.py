@@ -347,6 +347,58 @@ def test_fused_batched_pass_matches_oracle():
     idx.close()
 
 
+def test_two_stage_batched_pass_matches_oracle():
+    """Option "two_stage": the split GEMM only covers a sampled prefix; the corpus is screened by ONE
+    plain-bf16 product whose survivors are re-scored in the reference's arithmetic on the device.
+    Results must stay bit-identical, with and without a retry through the unfused pass."""
+    P = pkg()
+    rng = np.random.default_rng(78)
+    n, dim, B = 200_000, 128, 130
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    emb[150_000:150_040] = emb[150_000]          # 40 identical rows: ties across the floor
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "azure", "cosmos"])
+    contents = [" ".join(w) for w in words[rng.integers(0, len(words), (n, 5))]]
+    idx = P.RecallIndex(dim=dim)
+    step = 50_000
+    for r0 in range(0, n, step):
+        idx.append(emb[r0:r0 + step], created[r0:r0 + step], [c.encode() for c in contents[r0:r0 + step]])
+    idx.seal()
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[0] = emb[n - 7]
+    qs[1] = emb[123_456] * 3.0
+    qs[2] = emb[150_000]
+    qs[3] = 0.0                                  # normA == 0: cosine 0 everywhere, keyword + recency decide
+    qs[4] = emb[5] * 1e-3
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    corpus = orc.OracleCorpus(emb, created, contents)
+    for topk in (10, 30):
+        idx.set_option("two_stage", 0)
+        plain = idx.search(qs, terms, NOW, topk, candidate_limit=n)
+        idx.set_option("two_stage", 1)
+        idx.set_profiling(True)
+        rows, scores, counts = idx.search(qs, terms, NOW, topk, candidate_limit=n)
+        stats = idx.kernel_stats()
+        idx.set_profiling(False)
+        assert "gemm_dot_bf16x1_fused" in stats and "rescore_buffer_exact" in stats, stats.keys()
+        assert all(np.array_equal(x, y) for x, y in zip(plain, (rows, scores, counts)))
+        assert rows[0, 0] == n - 7 and rows[1, 0] == 123_456
+        for b in list(range(0, 8)) + [64, 129]:
+            orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=n, threads=8)
+            assert list(rows[b, :counts[b]]) == list(orow), (topk, b)
+            assert np.array_equal(scores[b, :counts[b]], osc), (topk, b)
+    # the sharded entry point takes the same route (floor from the k'-th best) and merges exactly
+    kprime = 32
+    recs = idx.search_shard(qs, terms, NOW, kprime, candidate_limit=n)
+    mrows, mscores, mcounts, unc = P.merge_candidates(recs[None], dim, qs, terms, NOW, 10)
+    assert unc == 0
+    idx.set_option("two_stage", 0)
+    plain = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    assert np.array_equal(mrows, plain[0]) and np.array_equal(mscores, plain[1])
+    idx.close()
+
+
 def test_empty_and_degenerate_inputs():
     """Empty corpus, rows with empty content, queries without terms or vectors, API misuse."""
     P = pkg()
