@@ -191,10 +191,18 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
- *   "two_stage"      0/1 (default 0): the same batches take ONE plain-bf16 product over all rows,
- *                    keep every row that could reach the k-th best score of a sampled prefix
- *                    (bound 2^-8 |q||e|), and re-score those exactly. */
+ *   "two_stage"      0/1/2 (default 0): the same batches take ONE plain-bf16 product over all rows
+ *                    (bound 2^-7 |q||e| on the dot), keep every (query,row) pair that could reach a lower
+ *                    bound of the query's k-th best score, and re-score those in the reference arithmetic on
+ *                    the device.  1: the product reads a bf16 shadow copy of the embeddings
+ *                    (built now if the index is sealed, +50 % HBM; silently falls back to 2 when it does not
+ *                    fit).  2: no shadow, the fp32 rows are converted inside the kernel. */
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
+
+/* Diagnostic: out[B][orr_index_rows] = the screening dots of the two-stage pass (fp32, host or device
+ * memory), i.e. sum_k bf16(q_k) bf16(e_k) accumulated in fp32 on the matrix cores.  Lets a test check the
+ * bound the pass relies on.  Needs the bf16 shadow (ORR_ENOMEM when it does not fit); dim % 64 == 0. */
+int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, float *out);
 
 /* ---- measurement ---------------------------------------------------------*/
 int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets the counters */

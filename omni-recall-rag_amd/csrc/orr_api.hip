@@ -156,10 +156,12 @@ struct orr_index {
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     bool sealed = false;
     bool opt_fuse_epilogue = false;
-    bool opt_two_stage = false;
+    int opt_two_stage = 0;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
+    DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
+    bool shadow_ready = false, shadow_failed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -425,10 +427,11 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
-                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
+    idx->emb_shadow.release();
     idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release();
     if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -784,13 +787,70 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
     return ORR_OK;
 }
 
+// bf16 shadow of the sealed embeddings for the screening GEMM.  Half the master's bytes; when the
+// allocation does not fit, the two-stage pass converts in the kernel instead (orr_gemm.hip, PROD = 1).
+static int ensure_shadow(orr_index *idx)
+{
+    if (idx->shadow_ready || idx->shadow_failed || !idx->sealed || idx->n_rows <= 0 || idx->dim <= 0 || idx->dim % 64 != 0) return ORR_OK;
+    const size_t bytes = orr::bf16_tiled_bytes(idx->n_rows, idx->dim);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + bytes / 8 + ((size_t)4 << 30)) {   // keep 4 GiB for workspaces
+        idx->shadow_failed = true;
+        return ORR_OK;
+    }
+    if (idx->emb_shadow.reserve(bytes) != ORR_OK) {
+        (void)hipGetLastError();
+        idx->shadow_failed = true;
+        return ORR_OK;
+    }
+    HIP_TRY(orr::launch_bf16_tiled(idx->d_emb, idx->n_rows, idx->dim, idx->emb_shadow.p, idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->shadow_ready = true;
+    return ORR_OK;
+}
+
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
 {
     if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
     std::lock_guard<std::mutex> lock(idx->mu);
     if (strcmp(name, "fuse_epilogue") == 0) { idx->opt_fuse_epilogue = value != 0; return ORR_OK; }
-    if (strcmp(name, "two_stage") == 0) { idx->opt_two_stage = value != 0; return ORR_OK; }
+    if (strcmp(name, "two_stage") == 0) {
+        if (value < 0 || value > 2) return fail(ORR_EINVAL, "orr_index_set_option: two_stage takes 0, 1 or 2");
+        idx->opt_two_stage = (int)value;
+        if (value == 1) {
+            HIP_TRY(hipSetDevice(idx->device));
+            ORR_TRY(ensure_shadow(idx));
+        }
+        return ORR_OK;
+    }
     return fail(ORR_EINVAL, "orr_index_set_option: unknown option %s", name);
+}
+
+int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, float *out)
+{
+    if (!idx || !q || !out || B <= 0) return fail(ORR_EINVAL, "orr_index_screen_dots: bad argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_screen_dots: the index is not sealed");
+    if (dim != idx->dim || dim <= 0 || dim % 64 != 0) return fail(ORR_EINVAL, "orr_index_screen_dots: dim must equal the index dimension and be a multiple of 64");
+    if (idx->n_rows <= 0) return ORR_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    ORR_TRY(ensure_shadow(idx));
+    if (!idx->shadow_ready) return fail(ORR_ENOMEM, "orr_index_screen_dots: the bf16 shadow does not fit in device memory");
+    hipStream_t s = idx->stream;
+    ORR_TRY(idx->ws_q.reserve(sizeof(float) * (size_t)B * dim));
+    ORR_TRY(idx->ws_qtiled.reserve(orr::bf16_tiled_bytes(B, dim)));
+    ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)idx->n_rows));
+    HIP_TRY(hipMemcpyAsync(idx->ws_q.p, q, sizeof(float) * (size_t)B * dim, hipMemcpyDefault, s));
+    HIP_TRY(orr::launch_bf16_tiled(idx->ws_q.as<float>(), B, dim, idx->ws_qtiled.p, s));
+    {
+        Timed t(idx, "screen_bf16", 2.0 * (double)idx->n_rows * dim + 2.0 * (double)B * dim + 4.0 * (double)B * (double)idx->n_rows);
+        HIP_TRY(orr::launch_screen_bf16(idx->ws_qtiled.p, B, idx->emb_shadow.p, 0, idx->n_rows, dim, idx->ws_dotf.as<float>(), idx->n_rows,
+                                        nullptr, s));
+    }
+    HIP_TRY(hipMemcpyAsync(out, idx->ws_dotf.p, sizeof(float) * (size_t)B * (size_t)idx->n_rows, hipMemcpyDefault, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    collect_events(idx);
+    return ORR_OK;
 }
 
 int orr_index_set_profiling(orr_index *idx, int32_t enabled)
@@ -977,7 +1037,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
                 HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
                 const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-                two_stage = idx->opt_two_stage && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
+                two_stage = idx->opt_two_stage != 0 && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
                 fused_sample_seg = ((idx->opt_fuse_epilogue || two_stage) && !a.no_fuse && n_seg_all >= 48)
                                        ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16)) : 0;
                 dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
@@ -1156,15 +1216,17 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                 idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, dotf_rows, B, 0, fused_sample_seg,
                                                 nullptr, idx->ws_sel.as<orr::SelEntry>(), lists_total, s));
             }
-            ORR_TRY(idx->ws_fqf.reserve(sizeof(float2) * (size_t)B));
+            ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * (size_t)B));
             orr::FusedEpilogue epi;
-            epi.any_bits = nullptr;
+            epi.count_planes = nullptr;
+            epi.plane_stride = (n + 63) / 64 * 64;
             if (kw.bitmaps) {
-                ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * (size_t)B * (size_t)kw.words_per_term));
-                HIP_TRY(orr::launch_query_any_bits(kw, B, idx->ws_fany.as<uint32_t>(), s));
-                epi.any_bits = idx->ws_fany.as<uint32_t>();
+                Timed t(idx, "count_planes", 4.0 * orr::kCountPlanes * (double)((B + 31) / 32) * (double)n);
+                ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
+                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s));
+                epi.count_planes = idx->ws_fany.as<uint32_t>();
             }
-            epi.qf = idx->ws_fqf.as<float2>();
+            epi.qf = idx->ws_fqf.as<float4>();
             epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw;
             epi.cnt = idx->ws_fcnt.as<uint32_t>(); epi.buf = idx->ws_fbuf.as<orr::SelEntry>(); epi.cap = kCap;
             HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
@@ -1184,9 +1246,15 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 HIP_TRY(orr::launch_two_stage_floor(d_tau, B, approx_eps, eps1, idx->ws_tskey.as<unsigned long long>(),
                                                     idx->ws_tsL.as<double>(), s));
                 HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
-                                                       idx->ws_fqf.as<float2>(), s));
+                                                       idx->ws_fqf.as<float4>(), s));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
-                {
+                if (idx->opt_two_stage == 1) ORR_TRY(ensure_shadow(idx));
+                if (idx->opt_two_stage == 1 && idx->shadow_ready) {
+                    ORR_TRY(idx->ws_qtiled.reserve(orr::bf16_tiled_bytes(B, idx->dim)));
+                    HIP_TRY(orr::launch_bf16_tiled(d_q, B, idx->dim, idx->ws_qtiled.p, s));
+                    Timed t(idx, "screen_bf16_fused", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
+                    HIP_TRY(orr::launch_screen_bf16(idx->ws_qtiled.p, B, idx->emb_shadow.p, 0, n, idx->dim, nullptr, 0, &epi, s));
+                } else {
                     Timed t(idx, "gemm_dot_bf16x1_fused", 4.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, n, idx->dim, nullptr, 0, &epi, 1, s));
                 }
@@ -1210,7 +1278,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 Timed t(idx, "select_floor", 0.0);
                 HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kprime, d_tau, s));
             }
-            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float2>(), s));
+            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float4>(), s));
             epi.tau = d_tau;
             {
                 Timed t(idx, "gemm_dot_bf16x3_fused", 4.0 * (double)(n - dotf_rows) * idx->dim + 4.0 * (double)B * idx->dim);

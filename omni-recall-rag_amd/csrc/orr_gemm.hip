@@ -9,13 +9,13 @@
 // result against the cut-off (orr_api.hip).
 #include "orr_kernels.h"
 #include "orr_device.h"
+#include "orr_epilogue.h"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace orr {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
@@ -141,8 +141,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__res
 // are placed on one XCD back to back, so later reads of the row tile come from that
 // XCD's L2 (default cache policy here).
 // ---------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kBfLd = 72;        // bf16 elements per LDS row (64 + 8 pad)
 
 __device__ __forceinline__ void split_write(__bf16 *hi_img, __bf16 *lo_img, int r, int c4, const float4 &v)
@@ -341,98 +339,77 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
                 }
             }
     } else {
-        // fp32 pre-filter first: an upper bound of the score (full keyword credit) against the
-        // query's floor; only the few pairs that pass pay for the fp64 score, the keyword bits
-        // and the atomic append.
-        float rb[NT], rr[NT];
-        int64_t cols[NT];
+        __syncthreads();                                                    // every wave is done with the operand images
+        fused_epilogue<2, NT>(acc, b0 + wm * 64, n0 + wn * 32 * NT, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(img) + tid, 512);
+    }
+}
+
+// Count planes: planes[p][g][r] bit q = bit p of the keyword match count of query 32 g + q in row r
+// (RecallSearchService.cs:111), so a lane of the scoring epilogue gets the counts of its 32
+// queries for one row from kCountPlanes words.  Queries with more than 15 terms store 15 where any
+// term occurs (the pre-filter then grants them the full keyword credit, an upper bound).
+__global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride,
+                                                                uint32_t *__restrict__ planes)
+{
+    const int g = blockIdx.y;
+    const int32_t n_qg = gridDim.y;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t w[kCountPlanes];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            cols[j] = n0 + wn * 32 * NT + j * 32 + fr;                     // this lane's row of E
-            const bool ok = cols[j] < n_rows;
-            const double2 rc = ok ? epi.rowc[cols[j]] : make_double2(0.0, 0.0);
-            rb[j] = ok ? (float)rc.x : 0.f;
-            rr[j] = ok ? (float)rc.y : -__builtin_huge_valf();             // rows past the end never pass
+        for (int p = 0; p < kCountPlanes; ++p) w[p] = 0u;
+        const int64_t word = r >> 5;
+        const uint32_t sh = (uint32_t)(r & 31);
+        for (int q = 0; q < 32; ++q) {
+            const int b = g * 32 + q;
+            if (b >= B) break;
+            const uint32_t t0 = kw.q_term_off[b], t1 = kw.q_term_off[b + 1];
+            uint32_t m = 0;
+            for (uint32_t i = t0; i < t1; ++i) m += (kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + word] >> sh) & 1u;
+            if (t1 - t0 > 15u) m = m ? 15u : 0u;
+#pragma unroll
+            for (int p = 0; p < kCountPlanes; ++p) w[p] |= ((m >> p) & 1u) << q;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qi = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int qc_i = qi < B ? qi : B - 1;
-                const float2 qf = epi.qf[qc_i];                            // {0.7/sqrt(normA), floor - margin}
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    // full keyword credit only where some term of the query occurs in the row at all
-                    float credit = 0.f;
-                    if (epi.any_bits) {
-                        const uint32_t w = epi.any_bits[(int64_t)qc_i * epi.kw.words_per_term + (cols[j] >> 5)];
-                        credit = ((w >> (cols[j] & 31)) & 1u) ? 0.2f : 0.f;
-                    }
-                    const float upper = acc[i][j][e] * (qf.x * rb[j]) + rr[j] + credit;
-                    if (upper < qf.y || qi >= B) continue;                  // NaN falls through to the exact test
-                    const QueryConst qc = epi.qc[qi];
-                    const double2 rc = epi.rowc[cols[j]];
-                    const uint32_t m = qc.n_terms > 0 ? kw_matches(epi.kw, qi, (uint32_t)cols[j]) : 0u;
-                    const unsigned long long key = score_key(fused_score_fast((double)acc[i][j][e], rc.x, rc.y, m, qc));
-                    if (key > epi.tau[qi]) {
-                        const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
-                        if (slot < epi.cap) {
-                            SelEntry en;
-                            en.key = key; en.pos = (uint32_t)cols[j]; en.pad = 0;
-                            epi.buf[(int64_t)qi * epi.cap + slot] = en;
-                        }
-                    }
-                }
-            }
+        for (int p = 0; p < kCountPlanes; ++p) planes[((int64_t)p * n_qg + g) * plane_stride + r] = w[p];
     }
 }
 
-// any_bits[b][w] = OR over the query's terms of the term bitmaps: "some term of b occurs in the row".
-__global__ __launch_bounds__(256) void query_any_bits_kernel(KwView kw, int32_t B, uint32_t *__restrict__ out)
+hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s)
 {
-    const int64_t total = (int64_t)B * kw.words_per_term;
-    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = id / kw.words_per_term, w = id - b * kw.words_per_term;
-        uint32_t acc = 0;
-        for (uint32_t i = kw.q_term_off[b]; i < kw.q_term_off[b + 1]; ++i)
-            acc |= kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + w];
-        out[id] = acc;
-    }
-}
-
-hipError_t launch_query_any_bits(KwView kw, int32_t B, uint32_t *out, hipStream_t s)
-{
-    if (B <= 0 || !kw.bitmaps) return hipSuccess;
-    int64_t blocks = ((int64_t)B * kw.words_per_term + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(query_any_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, kw, B, out);
+    if (B <= 0 || !kw.bitmaps || n_rows <= 0) return hipSuccess;
+    int64_t bx = (n_rows + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(query_count_planes_kernel, dim3((unsigned)bx, (unsigned)((B + 31) / 32)), dim3(256), 0, s, kw, B, n_rows,
+                       plane_stride, planes);
     return hipGetLastError();
 }
 
-// qf[b] = {0.7 / sqrt(normA) in fp32 (0 without cosine), floor score - margin}
+// qf[b] = {0.7 / sqrt(normA) in fp32 (0 without cosine), floor score - margin, keyword credit per match, 0}
 __global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryConst *__restrict__ qc,
                                                                  const unsigned long long *__restrict__ tau, int32_t B,
-                                                                 float2 *__restrict__ qf)
+                                                                 float4 *__restrict__ qf)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const QueryConst c = qc[b];
-    float2 o;
+    float4 o;
     o.x = c.use_cos ? (float)(c.inv_sqrt_na * 0.7) : 0.f;
     if (tau[b] <= 1ull) {
         o.y = -__builtin_huge_valf();                       // no floor (or a NaN floor): everything is tested exactly
     } else {
         const double floor_score = key_score(tau[b]);
-        // fp32 evaluation of cos*0.7 + rec*0.1 is off by < 2e-7 for scores of magnitude <= 1; 1e-5 margin,
-        // scaled up for larger magnitudes, and rounded down
+        // fp32 evaluation of cos*0.7 + kw*0.2 + rec*0.1 is off by < 1e-6 for scores of magnitude <= 1; 1e-5
+        // margin, scaled up for larger magnitudes, and rounded down
         const double margin = 1e-5 * (1.0 + fabs(floor_score));
         o.y = __double2float_rd(floor_score - margin);
     }
+    // count planes saturate at 15: beyond that a row with any match gets the full credit (15 * 0.2/15)
+    o.z = c.n_terms > 0 ? __double2float_ru(0.2 / (double)(c.n_terms > 15 ? 15 : c.n_terms)) : 0.f;
+    o.w = 0.f;
     qf[b] = o;
 }
 
-hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float2 *qf, hipStream_t s)
+hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(fused_query_consts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, qc, tau, B, qf);

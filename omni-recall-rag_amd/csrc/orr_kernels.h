@@ -13,6 +13,7 @@ constexpr int kSelWidth = 64;        // entries a wave keeps while selecting (on
 constexpr int kSelSegRows = 4096;    // rows one workgroup of fuse_select scans
 constexpr int kMaxExactQ = 8;        // queries one launch of the exact dot kernel carries
 constexpr int kMaxScanTerms = 64;    // query terms one launch of the keyword scan carries
+constexpr int kCountPlanes = 4;      // bit planes of the per-(query,row) keyword match count (saturates at 15)
 
 // One selection entry: `key` orders scores (see score_key in the .hip), `pos` is the
 // row's position in the shard's candidate order.  key 0 = empty slot.
@@ -123,8 +124,9 @@ struct FusedEpilogue {
     const QueryConst *qc;
     KwView kw;
     const unsigned long long *tau;     // [B] floor keys
-    const float2 *qf;                  // [B] fp32 pre-filter constants (launch_fused_query_consts)
-    const uint32_t *any_bits;          // [B][words_per_term] "some term of the query occurs in the row", or null
+    const float4 *qf;                  // [B] fp32 pre-filter constants (launch_fused_query_consts)
+    const uint32_t *count_planes;      // [kCountPlanes][ceil(B/32)][plane_stride] bit-sliced match counts, or null
+    int64_t plane_stride;
     uint32_t *cnt;                     // [B]
     SelEntry *buf;                     // [B][cap]
     uint32_t cap;
@@ -134,8 +136,14 @@ struct FusedEpilogue {
 hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_split_ws, hipStream_t s);
 hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
                                   float *S, int64_t s_stride, const FusedEpilogue *epi, int32_t products, hipStream_t s);
-hipError_t launch_query_any_bits(KwView kw, int32_t B, uint32_t *out, hipStream_t s);
-hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float2 *qf, hipStream_t s);
+hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s);
+hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s);
+// K2c (orr_screen.hip): plain-bf16 screening GEMM (256 x 256 x 64 tiles, LDS-DMA staging) over TILED bf16
+// images of the embeddings (the shard's shadow) and of the batch's queries; S or the fused epilogue as above.
+size_t bf16_tiled_bytes(int64_t n_rows, int32_t D);
+hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *out, hipStream_t s);
+hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shadow, int64_t row_first, int64_t n_rows,
+                              int32_t D, float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
 hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
                                   unsigned long long *floor_key, double *L_out, hipStream_t s);

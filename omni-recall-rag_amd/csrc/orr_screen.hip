@@ -1,0 +1,242 @@
+// orr_screen.hip -- K2c: the wide first stage of the two-stage batched pass.
+//
+// S[b][r] = sum_k hi(Q[b][k]) * hi(E[r][k]) with hi(x) = bf16(x), from a bf16 SHADOW of the
+// embedding matrix (built once per sealed shard, half the bytes of the fp32 master) and the hi
+// halves of the pre-split queries.  bf16 x bf16 products are exact in the fp32 accumulator, so
+//   |S - sum q_k e_k| <= [2^-7 (1 + 2^-9) + 1.02 D 2^-23] sum|q_k e_k|
+// (two bf16 roundings per product, u = 2^-8; every fp32 addition charged one full ulp).  The
+// pass never decides a result: it only drops (query,row) pairs whose score cannot reach a lower
+// bound of the query's k-th best score; everything it keeps is re-scored in the reference's own
+// arithmetic (RecallSearchService.cs:77-87) by rescore_buffer_exact (orr_gemm.hip).
+//
+// Structure (gfx950): one 256 (queries) x 256 (rows) tile per workgroup, 8 waves as 2 x 4, each
+// wave 128 x 64 = 4 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator VGPRs),
+// BK = 64.  Both operands are bf16 with k contiguous, so both go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write): two 64 KiB stages, one workgroup
+// barrier per K-tile, the next tile's 8 LDS-DMA pieces per thread in flight behind the MFMAs of
+// the current one.
+//
+// Memory layout: the shadow (and the hi halves of the queries) are stored TILED in exactly the
+// order of the LDS image -- [row tile of 256][K-tile of 64][256 rows][64 k] bf16, 32 KiB per
+// (row tile, K-tile) -- so a K-tile of an operand is ONE contiguous 32 KiB run of HBM and every
+// LDS-DMA piece (1 KiB per wave instruction, lane-linear) reads 1 KiB of consecutive addresses.
+// (Row-major, the same tile is 256 separate 128-byte pieces 6 KiB apart, and the kernel sat at
+// 3.4 TB/s of row-buffer-missing HBM reads whatever the instruction schedule.)  Within a row's
+// 128 bytes the 16-byte chunk c sits in slot c ^ ((row >> 1) & 7): that makes the
+// ds_read_b128 of an A/B fragment (32 rows x one chunk) conflict-free for the instruction's
+// four 16-lane groups (MI355X_MICROARCH.md, LDS), and because the swizzle is part of the stored
+// layout the copy stays linear.  Rows past the end of a tile are zero.  Workgroups that share a
+// row tile (B > 256) sit back to back on one XCD, so later reads of the tile come from that
+// XCD's L2.
+#include "orr_kernels.h"
+#include "orr_device.h"
+#include "orr_epilogue.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace orr {
+
+namespace {
+
+constexpr int kScBM = 256, kScBN = 256, kScBK = 64;
+constexpr int kScImage = kScBM * kScBK * 2;             // bytes of one operand image (32 KiB)
+constexpr int kScStage = 2 * kScImage;                  // A image | B image
+constexpr int kScLds = 2 * kScStage;                    // two stages = 128 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void glds16(const void *g, unsigned char *l)
+{
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, 0);
+}
+
+template <bool FUSED, int MODE>
+__global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
+                                                             const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
+                                                             int32_t D, float *__restrict__ S, int64_t s_stride,
+                                                             int32_t n_ntiles, int32_t n_mtiles, FusedEpilogue epi)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int mt = slot_id % n_mtiles, nt = (slot_id / n_mtiles) * 8 + xcd;
+    if (nt >= n_ntiles) return;
+    const int64_t n0 = row_first + (int64_t)nt * kScBN;
+    const int b0 = mt * kScBM;
+
+    // tiled operands: K-tile t of this workgroup's query tile / row tile is 32 KiB at base + t * 32 KiB;
+    // piece g of a tile (g < 4: A image, g >= 4: B image) is the KiB (g & 3) * 8 + wave of it
+    const int KT = D / kScBK;
+    const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * KT) * kScImage + wave * 1024 + lane * 16;
+    const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * KT) * kScImage + wave * 1024 + lane * 16;
+    auto issue_piece = [&](int t, int stage, int g) {
+        unsigned char *base = lds + stage * kScStage + wave * 1024 + (g & 3) * 8192 + (g >> 2) * kScImage;
+        if (MODE != 2) glds16((g < 4 ? a_src : b_src) + (int64_t)t * kScImage + (g & 3) * 8192, base);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 1) & 7)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int s0 = fh ^ ((fr >> 1) & 7);                                    // slot of ks = 0; ks flips bits 1..2
+    const int a_row = (wr * 128 + fr) * 128, b_row = kScImage + (wc * 64 + fr) * 128;
+
+    struct Frag { bf16x8 a[4], b[2]; };
+    auto read_frag = [&](Frag &f, const unsigned char *st, int ks) {
+        const int so = ((2 * ks) ^ s0) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 4096 + so);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_row + j * 4096 + so);
+    };
+    const int T = KT;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) issue_piece(0, 0, g);
+#define ORR_SB __builtin_amdgcn_sched_barrier(0)
+#define ORR_MM(f, i) \
+    if (MODE != 1) { \
+    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[0], acc[i][0], 0, 0, 0); \
+    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[1], acc[i][1], 0, 0, 0); } else { \
+    acc[i][0][0] += (float)f.a[i][0] + (float)f.b[0][0]; acc[i][1][0] += (float)f.a[i][1] + (float)f.b[1][0]; } ORR_SB
+    for (int t = 0; t < T; ++t) {
+        // tile t: own pieces landed, then everybody's; the same barrier says stage (t+1)&1 is no longer read
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned char *st = lds + (t & 1) * kScStage;
+        const int nx = (t + 1) & 1;
+        // Issue order is pinned.  The next tile's 8 pieces go out in the first half of the tile, one per
+        // pair of MFMAs: all 8 waves ask the one texture path for a piece every ~128 cycles, the time the
+        // SIMD's two waves need for four MFMAs, and every piece has half a tile or more to land.  The
+        // fragments of k-step ks+2 are read into the register set k-step ks has just released.
+        // (The last tile requests its own pieces again instead of branching around the requests: a branch
+        // here makes hipcc duplicate the MFMA chain and spill the accumulators.)
+        const int tn = t + 1 < T ? t + 1 : t;
+        Frag f0, f1;
+        read_frag(f0, st, 0); ORR_SB;
+        issue_piece(tn, nx, 0); issue_piece(tn, nx, 4); ORR_SB;
+        read_frag(f1, st, 1); ORR_SB;
+        ORR_MM(f0, 0); issue_piece(tn, nx, 1); ORR_SB;
+        ORR_MM(f0, 1); issue_piece(tn, nx, 5); ORR_SB;
+        ORR_MM(f0, 2); issue_piece(tn, nx, 2); ORR_SB;
+        ORR_MM(f0, 3); issue_piece(tn, nx, 6); ORR_SB;
+        read_frag(f0, st, 2); ORR_SB;
+        ORR_MM(f1, 0); issue_piece(tn, nx, 3); ORR_SB;
+        ORR_MM(f1, 1); issue_piece(tn, nx, 7); ORR_SB;
+        ORR_MM(f1, 2);
+        ORR_MM(f1, 3);
+        ORR_MM(f0, 0);
+        read_frag(f1, st, 3); ORR_SB;
+        ORR_MM(f0, 1); ORR_MM(f0, 2); ORR_MM(f0, 3);
+        ORR_MM(f1, 0); ORR_MM(f1, 1); ORR_MM(f1, 2); ORR_MM(f1, 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last tile's spare pieces
+#undef ORR_MM
+#undef ORR_SB
+
+    if (!FUSED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t col = n0 + wc * 64 + j * 32 + fr;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = b0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    if (row < B && col < n_rows && (MODE != 3 || acc[i][j][e] == 1.2345f)) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+                }
+            }
+    } else {
+        __syncthreads();                                                    // every wave is done with the operand images
+        fused_epilogue<4, 2>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+    }
+}
+
+// Tiled, pre-swizzled bf16 image of a row-major fp32 matrix X[n_rows][D] (see the header): output
+// chunk o (16 bytes) = 8 consecutive k of one row.  rows_padded = n_tiles * 256.
+__global__ __launch_bounds__(256) void bf16_tiled_kernel(const float *__restrict__ X, int64_t n_rows, int32_t D, int64_t n_chunks,
+                                                         __bf16 *__restrict__ out)
+{
+    const int KT = D / kScBK;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_chunks; o += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(o & 7);
+        const int rr = (int)((o >> 3) & 255);
+        const int64_t tk = o >> 11;                                        // tile * KT + kt
+        const int kt = (int)(tk % KT);
+        const int64_t row = (tk / KT) * kScBN + rr;
+        const int c = slot ^ ((rr >> 1) & 7);
+        bf16x8 h;
+        if (row < n_rows) {
+            const float *src = X + row * (int64_t)D + kt * kScBK + c * 8;
+            const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+            h[0] = (__bf16)v0.x; h[1] = (__bf16)v0.y; h[2] = (__bf16)v0.z; h[3] = (__bf16)v0.w;
+            h[4] = (__bf16)v1.x; h[5] = (__bf16)v1.y; h[6] = (__bf16)v1.z; h[7] = (__bf16)v1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8 *>(out + o * 8) = h;
+    }
+}
+
+}  // namespace
+
+// Bytes of the tiled bf16 image of an [n_rows][D] matrix.
+size_t bf16_tiled_bytes(int64_t n_rows, int32_t D)
+{
+    const int64_t tiles = (n_rows + kScBN - 1) / kScBN;
+    return (size_t)tiles * kScBN * (size_t)D * sizeof(uint16_t);
+}
+
+// out = tiled, pre-swizzled bf16(X) (round to nearest even); D % 64 == 0.
+hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *out, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    if (D <= 0 || D % kScBK != 0) return hipErrorInvalidValue;
+    const int64_t n_chunks = (int64_t)(bf16_tiled_bytes(n_rows, D) / 16);
+    const int64_t blocks = std::min<int64_t>((n_chunks + 255) / 256, 65536);
+    hipLaunchKernelGGL(bf16_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, n_rows, D, n_chunks, static_cast<__bf16 *>(out));
+    return hipGetLastError();
+}
+
+// Rows [row_first, n_rows) of the tiled shadow against the tiled hi halves of the queries
+// (launch_bf16_tiled of both).  epi == nullptr: dots to S; otherwise the fused epilogue.
+// D % 64 == 0, row_first % 256 == 0.
+hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shadow, int64_t row_first, int64_t n_rows,
+                              int32_t D, float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= row_first) return hipSuccess;
+    if (D % kScBK != 0 || D <= 0 || row_first % kScBN != 0) return hipErrorInvalidValue;
+    const int64_t n_ntiles = (n_rows - row_first + kScBN - 1) / kScBN;
+    const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
+    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const __bf16 *q_hi = static_cast<const __bf16 *>(q_tiled), *eh = static_cast<const __bf16 *>(e_shadow);
+    const FusedEpilogue none{};
+    // ORR_SCREEN_MODE (diagnostic, dots-to-S form only): 1 no MFMA, 2 no LDS-DMA, 3 no stores
+    static const int mode = [] { const char *e = getenv("ORR_SCREEN_MODE"); return e ? atoi(e) : 0; }();
+#define ORR_LAUNCH(F, M, E) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_bf16_kernel<F, M>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
+                           S, s_stride, (int32_t)n_ntiles, n_mtiles, E); } while (0)
+    if (epi) ORR_LAUNCH(true, 0, *epi);
+    else if (mode == 1) ORR_LAUNCH(false, 1, none);
+    else if (mode == 2) ORR_LAUNCH(false, 2, none);
+    else if (mode == 3) ORR_LAUNCH(false, 3, none);
+    else ORR_LAUNCH(false, 0, none);
+#undef ORR_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace orr

@@ -152,6 +152,14 @@ class RecallIndex:
     def set_option(self, name: str, value: int) -> None:
         N.check(N.hip.orr_index_set_option(self._h, name.encode(), int(value)))
 
+    def screen_dots(self, qvecs) -> np.ndarray:
+        """orr_index_screen_dots: the two-stage pass's plain-bf16 screening dots, [B, rows] fp32 (diagnostic)."""
+        q = np.ascontiguousarray(qvecs, dtype=np.float32)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        out = np.empty((q.shape[0], self.rows), dtype=np.float32)
+        N.check(N.hip.orr_index_screen_dots(self._h, int(q.shape[0]), int(q.shape[1]), _ptr(q), _ptr(out)))
+        return out
+
     def set_profiling(self, on: bool) -> None:
         N.check(N.hip.orr_index_set_profiling(self._h, 1 if on else 0))
 

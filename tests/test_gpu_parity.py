@@ -347,6 +347,33 @@ def test_fused_batched_pass_matches_oracle():
     idx.close()
 
 
+def test_screening_dots_stay_inside_the_bound_the_two_stage_pass_uses():
+    """orr_index_screen_dots: sum_k bf16(q_k) bf16(e_k) from the bf16 shadow, 256 x 256 x 64 LDS-DMA tiles.
+    Checked against a float64 evaluation of the same bf16-rounded operands (tight: only fp32
+    accumulation differs) and against the exact dot with the bound the pass relies on."""
+    import torch
+    P = pkg()
+    rng = np.random.default_rng(91)
+    for n, dim, B in ((777, 64, 3), (1000, 192, 70), (5000, 3072, 300)):
+        emb = (rng.standard_normal((n, dim)) * rng.choice([1e-3, 1.0, 50.0], (n, 1))).astype(np.float32)
+        created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+        idx = P.RecallIndex(dim=dim)
+        idx.append(emb, created, [b"x"] * n)
+        idx.seal()
+        qs = rng.standard_normal((B, dim)).astype(np.float32)
+        qs[0] = emb[n - 1]
+        got = idx.screen_dots(qs).astype(np.float64)
+        eh = torch.from_numpy(emb).to(torch.bfloat16).to(torch.float64).numpy()
+        qh = torch.from_numpy(qs).to(torch.bfloat16).to(torch.float64).numpy()
+        want_bf16 = qh @ eh.T
+        scale = np.abs(qh) @ np.abs(eh).T                                      # sum |q_k e_k| of the rounded operands
+        assert np.all(np.abs(got - want_bf16) <= 1.02 * dim * 2.0 ** -23 * scale + 1e-30), (n, dim, B)
+        exact = qs.astype(np.float64) @ emb.astype(np.float64).T
+        bound = (2.0 ** -7 * (1 + 2.0 ** -9) + 1.02 * dim * 2.0 ** -23) * (np.abs(qs).astype(np.float64) @ np.abs(emb).astype(np.float64).T)
+        assert np.all(np.abs(got - exact) <= bound + 1e-30), (n, dim, B)
+        idx.close()
+
+
 def test_two_stage_batched_pass_matches_oracle():
     """Option "two_stage": the split GEMM only covers a sampled prefix; the corpus is screened by ONE
     plain-bf16 product whose survivors are re-scored in the reference's arithmetic on the device.
@@ -373,15 +400,17 @@ def test_two_stage_batched_pass_matches_oracle():
     texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
     terms = [P.text.query_terms(t) for t in texts]
     corpus = orc.OracleCorpus(emb, created, contents)
-    for topk in (10, 30):
+    for topk, mode in ((10, 1), (30, 1), (10, 2), (30, 2)):
         idx.set_option("two_stage", 0)
         plain = idx.search(qs, terms, NOW, topk, candidate_limit=n)
-        idx.set_option("two_stage", 1)
+        idx.set_option("two_stage", mode)         # 1: bf16 shadow + LDS-DMA screening kernel; 2: converts in the kernel
         idx.set_profiling(True)
         rows, scores, counts = idx.search(qs, terms, NOW, topk, candidate_limit=n)
         stats = idx.kernel_stats()
         idx.set_profiling(False)
-        assert "gemm_dot_bf16x1_fused" in stats and "rescore_buffer_exact" in stats, stats.keys()
+        screen = "screen_bf16_fused" if mode == 1 else "gemm_dot_bf16x1_fused"
+        assert screen in stats and "rescore_buffer_exact" in stats, stats.keys()
+        assert stats["gemm_dot_bf16x3"]["launches"] == 1, stats       # no retry through the unfused pass
         assert all(np.array_equal(x, y) for x, y in zip(plain, (rows, scores, counts)))
         assert rows[0, 0] == n - 7 and rows[1, 0] == 123_456
         for b in list(range(0, 8)) + [64, 129]:
@@ -389,6 +418,7 @@ def test_two_stage_batched_pass_matches_oracle():
             assert list(rows[b, :counts[b]]) == list(orow), (topk, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (topk, b)
     # the sharded entry point takes the same route (floor from the k'-th best) and merges exactly
+    idx.set_option("two_stage", 1)
     kprime = 32
     recs = idx.search_shard(qs, terms, NOW, kprime, candidate_limit=n)
     mrows, mscores, mcounts, unc = P.merge_candidates(recs[None], dim, qs, terms, NOW, 10)
