@@ -156,7 +156,7 @@ struct orr_index {
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     bool sealed = false;
     bool opt_fuse_epilogue = false;
-    int opt_two_stage = 0;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
+    int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
     DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
     bool shadow_ready = false, shadow_failed = false;
 
@@ -1124,7 +1124,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         for (uint32_t i = 0; i < 65; ++i) iota[i] = i;
 
         const int64_t V = idx->n_tokens;
-        const int64_t words = (idx->n_rows + 31) / 32;
+        const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
         const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
         const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, 16u << 20);
         ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(V, 1)));

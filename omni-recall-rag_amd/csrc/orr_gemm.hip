@@ -348,36 +348,82 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
 // (RecallSearchService.cs:111), so a lane of the scoring epilogue gets the counts of its 32
 // queries for one row from kCountPlanes words.  Queries with more than 15 terms store 15 where any
 // term occurs (the pre-filter then grants them the full keyword credit, an upper bound).
+// One wave handles 256 rows x 32 queries at a time: lane (q, h) adds the row bitmaps of query q's
+// terms for the four bitmap words 8 pr + 4 h .. + 3 (one 16-byte load per term) bit-sliced -- 32 rows
+// per word, ripple carry through the planes -- then each plane of each word, a 32 x 32 bit matrix with
+// queries down the lanes and rows along the bits, is transposed across the lanes with five exchange
+// steps, after which lane (r, h) holds the word of row r.  words_per_term % 4 == 0.
 __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride,
                                                                 uint32_t *__restrict__ planes)
 {
     const int g = blockIdx.y;
     const int32_t n_qg = gridDim.y;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t w[kCountPlanes];
+    const int lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
+    const int b = g * 32 + q;
+    uint32_t t0 = 0, t1 = 0;
+    if (b < B) { t0 = kw.q_term_off[b]; t1 = kw.q_term_off[b + 1]; }
+    const bool saturate = t1 - t0 > 15u;
+    const int64_t n_quads = kw.words_per_term >> 2, n_oct = (n_quads + 1) >> 1;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t pr = wave_id; pr < n_oct; pr += n_waves) {
+        const int64_t Q = pr * 2 + h;                                      // this half-wave's group of four words
+        uint32_t c[4][kCountPlanes];
 #pragma unroll
-        for (int p = 0; p < kCountPlanes; ++p) w[p] = 0u;
-        const int64_t word = r >> 5;
-        const uint32_t sh = (uint32_t)(r & 31);
-        for (int q = 0; q < 32; ++q) {
-            const int b = g * 32 + q;
-            if (b >= B) break;
-            const uint32_t t0 = kw.q_term_off[b], t1 = kw.q_term_off[b + 1];
-            uint32_t m = 0;
-            for (uint32_t i = t0; i < t1; ++i) m += (kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + word] >> sh) & 1u;
-            if (t1 - t0 > 15u) m = m ? 15u : 0u;
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int p = 0; p < kCountPlanes; ++p) w[p] |= ((m >> p) & 1u) << q;
+            for (int p = 0; p < kCountPlanes; ++p) c[k][p] = 0u;
+        if (Q < n_quads) {
+            for (uint32_t i = t0; i < t1; ++i) {
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(kw.bitmaps + (int64_t)kw.q_term_idx[i] * kw.words_per_term + Q * 4);
+                const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t carry = wv[k];
+                    if (saturate) { c[k][0] |= carry; continue; }
+#pragma unroll
+                    for (int p = 0; p < kCountPlanes; ++p) {
+                        const uint32_t t = c[k][p] & carry;
+                        c[k][p] ^= carry;
+                        carry = t;
+                    }
+                }
+            }
+            if (saturate) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int p = 1; p < kCountPlanes; ++p) c[k][p] = c[k][0];
+            }
         }
 #pragma unroll
-        for (int p = 0; p < kCountPlanes; ++p) planes[((int64_t)p * n_qg + g) * plane_stride + r] = w[p];
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int p = 0; p < kCountPlanes; ++p) {
+                uint32_t x = c[k][p];
+#pragma unroll
+                for (int s = 4; s >= 0; --s) {
+                    const int jj = 1 << s;
+                    const uint32_t low = s == 4 ? 0x0000FFFFu : s == 3 ? 0x00FF00FFu : s == 2 ? 0x0F0F0F0Fu : s == 1 ? 0x33333333u : 0x55555555u;
+                    const uint32_t y = (uint32_t)__shfl_xor((int)x, jj, 64);
+                    x = (q & jj) ? (((y & ~low) >> jj) | (x & ~low)) : ((x & low) | ((y & low) << jj));
+                }
+                c[k][p] = x;
+            }
+            const int64_t row = (Q * 4 + k) * 32 + q;                      // after the transpose this lane holds row q of the word
+            if (row < n_rows) {
+#pragma unroll
+                for (int p = 0; p < kCountPlanes; ++p) planes[((int64_t)p * n_qg + g) * plane_stride + row] = c[k][p];
+            }
+        }
     }
 }
 
 hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s)
 {
     if (B <= 0 || !kw.bitmaps || n_rows <= 0) return hipSuccess;
-    int64_t bx = (n_rows + 255) / 256;
+    if (kw.words_per_term % 4 != 0) return hipErrorInvalidValue;
+    const int64_t n_oct = (kw.words_per_term / 4 + 1) / 2;
+    int64_t bx = (n_oct + 3) / 4;                                          // 4 waves per workgroup
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(query_count_planes_kernel, dim3((unsigned)bx, (unsigned)((B + 31) / 32)), dim3(256), 0, s, kw, B, n_rows,
                        plane_stride, planes);

@@ -384,9 +384,21 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restric
         const uint64_t b0 = h.post_begin + (uint64_t)(c - h.chunk_base) * kPostChunk;
         const uint64_t b1 = b0 + kPostChunk < h.post_end ? b0 + kPostChunk : h.post_end;
         uint32_t *bm = bitmaps + (int64_t)h.term * words_per_term;
-        for (uint64_t p = b0 + lane; p < b1; p += 64) {
-            const uint32_t row = post_rows[p];
-            atomicOr(&bm[row >> 5], 1u << (row & 31));
+        // posting rows ascend, so the lanes that hit one bitmap word are neighbours: OR their bits
+        // together (segmented, 5 steps: a word has 32 bits) and let the last lane of each run do the atomic
+        for (uint64_t p0 = b0; p0 < b1; p0 += 64) {
+            const uint64_t p = p0 + lane;
+            const bool live = p < b1;
+            const uint32_t row = live ? post_rows[p] : 0xFFFFFFFFu;
+            const uint32_t word = row >> 5;
+            uint32_t bits = live ? 1u << (row & 31) : 0u;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t ow = (uint32_t)__shfl_up((int)word, d, 64), ob = (uint32_t)__shfl_up((int)bits, d, 64);
+                if (lane >= d && ow == word) bits |= ob;
+            }
+            const uint32_t nw = (uint32_t)__shfl_down((int)word, 1, 64);
+            if (live && (lane == 63 || nw != word)) atomicOr(&bm[word], bits);
         }
     }
 }

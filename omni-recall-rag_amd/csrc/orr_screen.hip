@@ -10,19 +10,20 @@
 // arithmetic (RecallSearchService.cs:77-87) by rescore_buffer_exact (orr_gemm.hip).
 //
 // Structure (gfx950): one 256 (queries) x 256 (rows) tile per workgroup, 8 waves as 2 x 4, each
-// wave 128 x 64 = 4 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator VGPRs),
-// BK = 64.  Both operands are bf16 with k contiguous, so both go global -> LDS with
-// global_load_lds_dwordx4 (no VGPR staging, no ds_write): two 64 KiB stages, one workgroup
-// barrier per K-tile, the next tile's 8 LDS-DMA pieces per thread in flight behind the MFMAs of
-// the current one.
+// wave 128 x 64 = 4 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator VGPRs).
+// Both operands are bf16 with k contiguous, so both go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write) into a ring of five 32 KiB stages
+// (all 160 KiB of LDS), one K-tile of 32 per stage.  One workgroup barrier per K-tile; the
+// LDS-DMA pieces of three K-tiles (96 KiB) stay in flight across it behind a counted
+// s_waitcnt vmcnt -- with one 64 KiB tile in flight the loads of a CU were latency-bound at
+// 29 GB/s, HBM stream and L2-resident queries together.  The fragments of K-tile t+1 are read
+// into a second register set while K-tile t is multiplied, so no MFMA waits for LDS.
 //
 // Memory layout: the shadow (and the hi halves of the queries) are stored TILED in exactly the
-// order of the LDS image -- [row tile of 256][K-tile of 64][256 rows][64 k] bf16, 32 KiB per
-// (row tile, K-tile) -- so a K-tile of an operand is ONE contiguous 32 KiB run of HBM and every
+// order of the LDS image -- [row tile of 256][K-tile of 32][256 rows][32 k] bf16, 16 KiB per
+// (row tile, K-tile) -- so a K-tile of an operand is ONE contiguous 16 KiB run of HBM and every
 // LDS-DMA piece (1 KiB per wave instruction, lane-linear) reads 1 KiB of consecutive addresses.
-// (Row-major, the same tile is 256 separate 128-byte pieces 6 KiB apart, and the kernel sat at
-// 3.4 TB/s of row-buffer-missing HBM reads whatever the instruction schedule.)  Within a row's
-// 128 bytes the 16-byte chunk c sits in slot c ^ ((row >> 1) & 7): that makes the
+// Within a row's 64 bytes the 16-byte chunk c sits in slot c ^ ((row >> 2) & 3): that makes the
 // ds_read_b128 of an A/B fragment (32 rows x one chunk) conflict-free for the instruction's
 // four 16-lane groups (MI355X_MICROARCH.md, LDS), and because the swizzle is part of the stored
 // layout the copy stays linear.  Rows past the end of a tile are zero.  Workgroups that share a
@@ -39,10 +40,11 @@ namespace orr {
 
 namespace {
 
-constexpr int kScBM = 256, kScBN = 256, kScBK = 64;
-constexpr int kScImage = kScBM * kScBK * 2;             // bytes of one operand image (32 KiB)
+constexpr int kScBM = 256, kScBN = 256, kScBK = 32;
+constexpr int kScImage = kScBM * kScBK * 2;             // bytes of one operand image (16 KiB)
 constexpr int kScStage = 2 * kScImage;                  // A image | B image
-constexpr int kScLds = 2 * kScStage;                    // two stages = 128 KiB
+constexpr int kScNS = 5;                                // stages in the ring
+constexpr int kScLds = kScNS * kScStage;                // 160 KiB
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -69,14 +71,15 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     const int64_t n0 = row_first + (int64_t)nt * kScBN;
     const int b0 = mt * kScBM;
 
-    // tiled operands: K-tile t of this workgroup's query tile / row tile is 32 KiB at base + t * 32 KiB;
-    // piece g of a tile (g < 4: A image, g >= 4: B image) is the KiB (g & 3) * 8 + wave of it
-    const int KT = D / kScBK;
-    const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * KT) * kScImage + wave * 1024 + lane * 16;
-    const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * KT) * kScImage + wave * 1024 + lane * 16;
-    auto issue_piece = [&](int t, int stage, int g) {
-        unsigned char *base = lds + stage * kScStage + wave * 1024 + (g & 3) * 8192 + (g >> 2) * kScImage;
-        if (MODE != 2) glds16((g < 4 ? a_src : b_src) + (int64_t)t * kScImage + (g & 3) * 8192, base);
+    // tiled operands: K-tile t of this workgroup's query tile / row tile is 16 KiB at base + t * 16 KiB;
+    // piece g of a tile (g < 2: A image, g >= 2: B image) is the KiB (g & 1) * 8 + wave of it
+    const int T = D / kScBK;
+    const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * T) * kScImage + wave * 1024 + lane * 16;
+    const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * T) * kScImage + wave * 1024 + lane * 16;
+    auto issue_piece = [&](int t, int g) {
+        const int tc = t < T ? t : T - 1;                                   // past the end: a spare copy of the last tile
+        unsigned char *base = lds + (t % kScNS) * kScStage + wave * 1024 + (g & 1) * 8192 + (g >> 1) * kScImage;
+        if (MODE != 2 && !(MODE == 4 && g < 2) && !(MODE == 5 && g >= 2)) glds16((g < 2 ? a_src : b_src) + (int64_t)tc * kScImage + (g & 1) * 8192, base);
     };
 
     f32x16 acc[4][2];
@@ -87,61 +90,65 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 1) & 7)
+    // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
     const int fr = lane & 31, fh = lane >> 5;
-    const int s0 = fh ^ ((fr >> 1) & 7);                                    // slot of ks = 0; ks flips bits 1..2
-    const int a_row = (wr * 128 + fr) * 128, b_row = kScImage + (wc * 64 + fr) * 128;
+    const int s0 = fh ^ ((fr >> 2) & 3);                                    // slot of ks = 0; ks = 1 flips bit 1
+    const int a_row = (wr * 128 + fr) * 64, b_row = kScImage + (wc * 64 + fr) * 64;
 
     struct Frag { bf16x8 a[4], b[2]; };
-    auto read_frag = [&](Frag &f, const unsigned char *st, int ks) {
+    auto read_frag = [&](Frag &f, int t, int ks) {
+        const unsigned char *st = lds + (t % kScNS) * kScStage;
         const int so = ((2 * ks) ^ s0) * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 4096 + so);
+        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 2048 + so);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_row + j * 4096 + so);
+        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_row + j * 2048 + so);
     };
-    const int T = KT;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) issue_piece(0, 0, g);
+
 #define ORR_SB __builtin_amdgcn_sched_barrier(0)
 #define ORR_MM(f, i) \
-    if (MODE != 1) { \
+    if (MODE != 1 && MODE != 4 && MODE != 5) { \
     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[0], acc[i][0], 0, 0, 0); \
     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[1], acc[i][1], 0, 0, 0); } else { \
     acc[i][0][0] += (float)f.a[i][0] + (float)f.b[0][0]; acc[i][1][0] += (float)f.a[i][1] + (float)f.b[1][0]; } ORR_SB
-    for (int t = 0; t < T; ++t) {
-        // tile t: own pieces landed, then everybody's; the same barrier says stage (t+1)&1 is no longer read
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const unsigned char *st = lds + (t & 1) * kScStage;
-        const int nx = (t + 1) & 1;
-        // Issue order is pinned.  The next tile's 8 pieces go out in the first half of the tile, one per
-        // pair of MFMAs: all 8 waves ask the one texture path for a piece every ~128 cycles, the time the
-        // SIMD's two waves need for four MFMAs, and every piece has half a tile or more to land.  The
-        // fragments of k-step ks+2 are read into the register set k-step ks has just released.
-        // (The last tile requests its own pieces again instead of branching around the requests: a branch
-        // here makes hipcc duplicate the MFMA chain and spill the accumulators.)
-        const int tn = t + 1 < T ? t + 1 : t;
-        Frag f0, f1;
-        read_frag(f0, st, 0); ORR_SB;
-        issue_piece(tn, nx, 0); issue_piece(tn, nx, 4); ORR_SB;
-        read_frag(f1, st, 1); ORR_SB;
-        ORR_MM(f0, 0); issue_piece(tn, nx, 1); ORR_SB;
-        ORR_MM(f0, 1); issue_piece(tn, nx, 5); ORR_SB;
-        ORR_MM(f0, 2); issue_piece(tn, nx, 2); ORR_SB;
-        ORR_MM(f0, 3); issue_piece(tn, nx, 6); ORR_SB;
-        read_frag(f0, st, 2); ORR_SB;
-        ORR_MM(f1, 0); issue_piece(tn, nx, 3); ORR_SB;
-        ORR_MM(f1, 1); issue_piece(tn, nx, 7); ORR_SB;
-        ORR_MM(f1, 2);
-        ORR_MM(f1, 3);
-        ORR_MM(f0, 0);
-        read_frag(f1, st, 3); ORR_SB;
-        ORR_MM(f0, 1); ORR_MM(f0, 2); ORR_MM(f0, 3);
-        ORR_MM(f1, 0); ORR_MM(f1, 1); ORR_MM(f1, 2); ORR_MM(f1, 3);
+    // One K-tile: CUR holds the fragments of tile t (read an iteration ago), NXT receives those of tile t+1.
+    // Counted wait: 4 pieces per tile per thread; behind tile t+1 the tiles t+2 .. t+NS-2 may still be in
+    // flight.  The barrier makes tile t+1 visible and says nobody reads stage (t-1) % NS any more, which
+    // tile t+NS-1 then takes.  Issue order is pinned, and the first MFMAs go out before the next fragments
+    // are requested (the compiler's lgkmcnt(0) ahead of them then only covers reads that completed an
+    // iteration ago).
+    // One LDS-DMA piece per pair of MFMAs in the first half of the tile.  (Measured alternatives, 1M x 3072
+    // rows x 256 queries: all four pieces right after the barrier, or the SIMD's two waves taking the
+    // request half and the multiply half of the period in opposite order: both 5-8 % slower.)
+#define ORR_TILE(CUR0, CUR1, NXT0, NXT1, t) \
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (kScNS - 3)) : "memory"); \
+    issue_piece((t) + kScNS - 1, 0); ORR_SB; \
+    ORR_MM(CUR0, 0); \
+    read_frag(NXT0, (t) + 1, 0); ORR_SB; \
+    ORR_MM(CUR0, 1); issue_piece((t) + kScNS - 1, 2); ORR_SB; \
+    ORR_MM(CUR0, 2); issue_piece((t) + kScNS - 1, 1); ORR_SB; \
+    ORR_MM(CUR0, 3); issue_piece((t) + kScNS - 1, 3); ORR_SB; \
+    ORR_MM(CUR1, 0); \
+    read_frag(NXT1, (t) + 1, 1); ORR_SB; \
+    ORR_MM(CUR1, 1); ORR_MM(CUR1, 2); ORR_MM(CUR1, 3)
+
+    // prologue: tiles 0 .. NS-2 requested; tile 0 awaited and read
+#pragma unroll
+    for (int t = 0; t < kScNS - 1; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) issue_piece(t, g);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (kScNS - 2)) : "memory");
+    Frag fa0, fa1, fb0, fb1;
+    read_frag(fa0, 0, 0);
+    read_frag(fa1, 0, 1);
+    for (int t = 0; t < T; t += 2) {                                        // T = D / 32 is even
+        ORR_TILE(fa0, fa1, fb0, fb1, t);
+        ORR_TILE(fb0, fb1, fa0, fa1, t + 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the last tile's spare pieces
+#undef ORR_TILE
 #undef ORR_MM
 #undef ORR_SB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the spare pieces of the last tiles
 
     if (!FUSED) {
 #pragma unroll
@@ -168,12 +175,12 @@ __global__ __launch_bounds__(256) void bf16_tiled_kernel(const float *__restrict
 {
     const int KT = D / kScBK;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_chunks; o += (int64_t)gridDim.x * blockDim.x) {
-        const int slot = (int)(o & 7);
-        const int rr = (int)((o >> 3) & 255);
-        const int64_t tk = o >> 11;                                        // tile * KT + kt
+        const int slot = (int)(o & 3);
+        const int rr = (int)((o >> 2) & 255);
+        const int64_t tk = o >> 10;                                        // tile * KT + kt
         const int kt = (int)(tk % KT);
         const int64_t row = (tk / KT) * kScBN + rr;
-        const int c = slot ^ ((rr >> 1) & 7);
+        const int c = slot ^ ((rr >> 2) & 3);
         bf16x8 h;
         if (row < n_rows) {
             const float *src = X + row * (int64_t)D + kt * kScBK + c * 8;
@@ -201,7 +208,7 @@ size_t bf16_tiled_bytes(int64_t n_rows, int32_t D)
 hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *out, hipStream_t s)
 {
     if (n_rows <= 0) return hipSuccess;
-    if (D <= 0 || D % kScBK != 0) return hipErrorInvalidValue;
+    if (D <= 0 || D % 64 != 0) return hipErrorInvalidValue;
     const int64_t n_chunks = (int64_t)(bf16_tiled_bytes(n_rows, D) / 16);
     const int64_t blocks = std::min<int64_t>((n_chunks + 255) / 256, 65536);
     hipLaunchKernelGGL(bf16_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, n_rows, D, n_chunks, static_cast<__bf16 *>(out));
@@ -215,14 +222,15 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
                               int32_t D, float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s)
 {
     if (B <= 0 || n_rows <= row_first) return hipSuccess;
-    if (D % kScBK != 0 || D <= 0 || row_first % kScBN != 0) return hipErrorInvalidValue;
+    if (D % 64 != 0 || D <= 0 || row_first % kScBN != 0) return hipErrorInvalidValue;
     const int64_t n_ntiles = (n_rows - row_first + kScBN - 1) / kScBN;
     const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const __bf16 *q_hi = static_cast<const __bf16 *>(q_tiled), *eh = static_cast<const __bf16 *>(e_shadow);
     const FusedEpilogue none{};
-    // ORR_SCREEN_MODE (diagnostic, dots-to-S form only): 1 no MFMA, 2 no LDS-DMA, 3 no stores
+    // ORR_SCREEN_MODE (diagnostic, dots-to-S form only): 1 no MFMA, 2 no LDS-DMA, 3 no stores,
+    // 4 no MFMA and no query pieces, 5 no MFMA and no row pieces
     static const int mode = [] { const char *e = getenv("ORR_SCREEN_MODE"); return e ? atoi(e) : 0; }();
 #define ORR_LAUNCH(F, M, E) do { \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M>), \
@@ -234,6 +242,8 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     else if (mode == 1) ORR_LAUNCH(false, 1, none);
     else if (mode == 2) ORR_LAUNCH(false, 2, none);
     else if (mode == 3) ORR_LAUNCH(false, 3, none);
+    else if (mode == 4) ORR_LAUNCH(false, 4, none);
+    else if (mode == 5) ORR_LAUNCH(false, 5, none);
     else ORR_LAUNCH(false, 0, none);
 #undef ORR_LAUNCH
     return hipGetLastError();

@@ -329,7 +329,8 @@ def test_fused_batched_pass_matches_oracle():
     qs[1] = emb[123_456] * 3.0
     texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
     terms = [P.text.query_terms(t) for t in texts]
-    plain = idx.search(qs, terms, NOW, 10, candidate_limit=n)          # default: dots through HBM
+    idx.set_option("two_stage", 0)
+    plain = idx.search(qs, terms, NOW, 10, candidate_limit=n)          # split pass, dots through HBM
     idx.set_option("fuse_epilogue", 1)
     with pytest.raises(P.OrrError):
         idx.set_option("no_such_option", 1)
@@ -383,6 +384,7 @@ def test_two_stage_batched_pass_matches_oracle():
     n, dim, B = 200_000, 128, 130
     emb = rng.standard_normal((n, dim)).astype(np.float32)
     emb[150_000:150_040] = emb[150_000]          # 40 identical rows: ties across the floor
+    emb[100_000:120_000] = emb[100_000]          # 20,000 identical rows: more survivors than a query's buffer holds
     created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
     words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "azure", "cosmos"])
     contents = [" ".join(w) for w in words[rng.integers(0, len(words), (n, 5))]]
@@ -400,6 +402,16 @@ def test_two_stage_batched_pass_matches_oracle():
     texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
     terms = [P.text.query_terms(t) for t in texts]
     corpus = orc.OracleCorpus(emb, created, contents)
+    # a query on the 20,000 identical rows overflows its survivor buffer: the batch is repeated unfused
+    q_over = qs.copy()
+    q_over[5] = emb[100_000]
+    idx.set_profiling(True)
+    rows, scores, counts = idx.search(q_over, terms, NOW, 10, candidate_limit=n)
+    assert idx.kernel_stats()["gemm_dot_bf16x3"]["launches"] == 2      # prefix pass + the unfused repeat
+    idx.set_profiling(False)
+    for b in (0, 5, 6):
+        orow, osc, _ = corpus.search(q_over[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+        assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), b
     for topk, mode in ((10, 1), (30, 1), (10, 2), (30, 2)):
         idx.set_option("two_stage", 0)
         plain = idx.search(qs, terms, NOW, topk, candidate_limit=n)
