@@ -49,16 +49,17 @@ constexpr int kScLds = kScNS * kScStage;                // 160 KiB
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+template <int AUX>
 __device__ __forceinline__ void glds16(const void *g, unsigned char *l)
 {
-    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, AUX);
 }
 
 template <bool FUSED, int MODE>
 __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
                                                              const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
                                                              int32_t D, float *__restrict__ S, int64_t s_stride,
-                                                             int32_t n_ntiles, int32_t n_mtiles, FusedEpilogue epi)
+                                                             int32_t n_ntiles, int32_t n_mtiles, int32_t flags, FusedEpilogue epi)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,10 +77,16 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     const int T = D / kScBK;
     const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * T) * kScImage + wave * 1024 + lane * 16;
     const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * T) * kScImage + wave * 1024 + lane * 16;
+    const bool stream_rows = n_mtiles == 1 && (flags & 1);
     auto issue_piece = [&](int t, int g) {
         const int tc = t < T ? t : T - 1;                                   // past the end: a spare copy of the last tile
         unsigned char *base = lds + (t % kScNS) * kScStage + wave * 1024 + (g & 1) * 8192 + (g >> 1) * kScImage;
-        if (MODE != 2 && !(MODE == 4 && g < 2) && !(MODE == 5 && g >= 2)) glds16((g < 2 ? a_src : b_src) + (int64_t)tc * kScImage + (g & 1) * 8192, base);
+        if (MODE == 2 || (MODE == 4 && g < 2) || (MODE == 5 && g >= 2)) return;
+        // rows are streamed once when the whole batch fits one query tile: non-temporal, so they do not push
+        // the query images (re-read by every workgroup) out of L2
+        if (g < 2) glds16<0>(a_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
+        else if (stream_rows) glds16<2>(b_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
+        else glds16<0>(b_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
     };
 
     f32x16 acc[4][2];
@@ -232,12 +239,13 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     // ORR_SCREEN_MODE (diagnostic, dots-to-S form only): 1 no MFMA, 2 no LDS-DMA, 3 no stores,
     // 4 no MFMA and no query pieces, 5 no MFMA and no row pieces
     static const int mode = [] { const char *e = getenv("ORR_SCREEN_MODE"); return e ? atoi(e) : 0; }();
+    static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
 #define ORR_LAUNCH(F, M, E) do { \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<F, M>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
-                           S, s_stride, (int32_t)n_ntiles, n_mtiles, E); } while (0)
+                           S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, E); } while (0)
     if (epi) ORR_LAUNCH(true, 0, *epi);
     else if (mode == 1) ORR_LAUNCH(false, 1, none);
     else if (mode == 2) ORR_LAUNCH(false, 2, none);

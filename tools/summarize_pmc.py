@@ -16,7 +16,7 @@ for f in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if want in k:
-            name = k.split("(")[0].replace("void ", "")
+            name = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for name, cs in agg.items():
