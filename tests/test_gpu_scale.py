@@ -70,3 +70,39 @@ def test_candidate_limit_prefix_against_oracle_at_1m(big):
         r300, s300, _ = idx.search(q, [P.text.query_terms(text)], syn.NOW_TICKS, 10, candidate_limit=300)
         o300, os300, _ = cor.search(q[0], text, syn.NOW_TICKS, 10, candidate_limit=300)
         assert list(r300[0]) == list(o300) and np.array_equal(s300[0], os300)
+
+
+def test_batched_passes_equal_the_exact_pass_at_1m(big):
+    """256 queries at the bench size: the two-stage pass (screening GEMM over the bf16 shadow, exact
+    re-score), its shadow-less form and the split-bf16 pass must all return exactly what the
+    reference-arithmetic kernel returns four queries at a time -- rows, order and fp64 scores."""
+    P, syn, idx, n, dim = big
+    B = 256
+    q = syn.query_vectors(1000, B, dim, n, "cuda:0")
+    texts = syn.query_texts(1000, B, n)
+    terms = [P.text.query_terms(t) for t in texts]
+    exact_rows = np.empty((B, 10), dtype=np.int64)
+    exact_scores = np.empty((B, 10), dtype=np.float64)
+    for b0 in range(0, B, 4):
+        r, s, c = idx.search(q[b0:b0 + 4], terms[b0:b0 + 4], syn.NOW_TICKS, 10, candidate_limit=n)
+        assert (c == 10).all()
+        exact_rows[b0:b0 + 4], exact_scores[b0:b0 + 4] = r, s
+    assert list(exact_rows[:, 0]) == syn.planted_rows(1000, B, n)
+    for mode in (1, 2, 0):
+        idx.set_option("two_stage", mode)
+        idx.set_profiling(True)
+        r, s, c = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n)
+        stats = idx.kernel_stats()
+        idx.set_profiling(False)
+        assert np.array_equal(r, exact_rows) and np.array_equal(s, exact_scores), mode
+        if mode:
+            assert ("screen_bf16_fused" if mode == 1 else "gemm_dot_bf16x1_fused") in stats
+            assert stats["gemm_dot_bf16x3"]["launches"] == 1          # certified without a repeat
+    idx.set_option("two_stage", 1)
+    # a candidate_limit that cuts the corpus goes through the same pass on the prefix
+    m = 600_000
+    r, s, c = idx.search(q[:96], terms[:96], syn.NOW_TICKS, 10, candidate_limit=m)
+    for b0 in range(0, 8, 4):
+        r4, s4, _ = idx.search(q[b0:b0 + 4], terms[b0:b0 + 4], syn.NOW_TICKS, 10, candidate_limit=m)
+        assert np.array_equal(r[b0:b0 + 4], r4) and np.array_equal(s[b0:b0 + 4], s4)
+    assert (r < m).all()
