@@ -154,6 +154,7 @@ struct orr_index {
     std::vector<int64_t> h_created;    // host mirror (seal-time ordering)
     std::vector<uint32_t> h_clen;      // host mirror of content lengths
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
+    std::vector<double> h_norm_a;      // exact query norms of the batch in flight (run_shard -> host finish)
     bool sealed = false;
     bool opt_fuse_epilogue = false;
     int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
@@ -306,6 +307,24 @@ double exact_norm(const float *q, int32_t dim)
         acc += (double)p;
     }
     return acc;
+}
+
+// The same sums for a batch.  Each query's sum is a chain of dependent fp64 additions (the order is
+// part of the reference's arithmetic), so eight queries are walked in lock step to keep the adder busy.
+void exact_norms(const float *q, int32_t B, int32_t dim, double *out)
+{
+    int32_t b = 0;
+    for (; b + 8 <= B; b += 8) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float *r = q + (size_t)b * dim;
+        for (int32_t i = 0; i < dim; ++i)
+            for (int j = 0; j < 8; ++j) {
+                float p = r[(size_t)j * dim + i] * r[(size_t)j * dim + i];
+                acc[j] += (double)p;
+            }
+        for (int j = 0; j < 8; ++j) out[b + j] = acc[j];
+    }
+    for (; b < B; ++b) out[b] = exact_norm(q + (size_t)b * dim, dim);
 }
 
 // double.CompareTo
@@ -1019,7 +1038,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
             d_dotf = idx->ws_dotf.as<float>();
         }
-        if (B <= 64) {   // HBM-bound streaming form, 32 queries per launch (two launches at most)
+        // 33..64 queries: two streaming launches (5.2 ms at 1M rows) lose to the two-stage pass (3.5 ms) where it applies
+        const bool ts_eligible = idx->opt_two_stage != 0 && !a.no_fuse && (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 &&
+                                 std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
+        if (B <= 32 || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form, 32 queries per launch (two launches at most)
             for (int32_t b0 = 0; b0 < B; b0 += 32) {
                 const int32_t nq = std::min<int32_t>(32, B - b0);
                 Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);
@@ -1171,9 +1193,11 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     orr::QueryConst *qc = idx->pin_qc.as<orr::QueryConst>();
+    idx->h_norm_a.assign((size_t)B, 0.0);
+    if (use_cos) exact_norms(idx->pin_q.as<float>(), B, a.dim, idx->h_norm_a.data());
     for (int32_t b = 0; b < B; ++b) {
         qc[b].use_cos = use_cos ? 1 : 0;
-        qc[b].norm_a = use_cos ? exact_norm(idx->pin_q.as<float>() + (size_t)b * a.dim, a.dim) : 0.0;
+        qc[b].norm_a = idx->h_norm_a[(size_t)b];
         qc[b].n_terms = (int32_t)(qoff[b + 1] - qoff[b]);
         qc[b].inv_n_terms = qc[b].n_terms > 0 ? 1.0 / (double)qc[b].n_terms : 0.0;
         qc[b].inv_sqrt_na = 0.0;
@@ -1441,16 +1465,22 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
 }
 
 int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all, int32_t dim, bool use_cos,
-               const float *q_host, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+               const float *q_host, const double *norms, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
                int64_t *out_rows, double *out_scores, int32_t *out_counts, int32_t *out_uncertified)
 {
     const int32_t take = std::max<int32_t>(1, topk);
     int32_t unc = 0;
+    std::vector<double> own_norms;
+    if (use_cos && !norms) {
+        own_norms.resize((size_t)B);
+        exact_norms(q_host, B, dim, own_norms.data());
+        norms = own_norms.data();
+    }
     std::vector<const orr_candidate *> recs((size_t)n_shards);
     for (int32_t b = 0; b < B; ++b) {
         for (int32_t sidx = 0; sidx < n_shards; ++sidx)
             recs[sidx] = all + ((size_t)sidx * B + b) * ((size_t)kprime + 1);
-        const double norm_a = use_cos ? exact_norm(q_host + (size_t)b * dim, dim) : 0.0;
+        const double norm_a = use_cos ? norms[b] : 0.0;
         const int32_t n_terms = (int32_t)(query_term_off[b + 1] - query_term_off[b]);
         bool cert = false;
         int err = ORR_OK;
@@ -1493,7 +1523,7 @@ int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_
     if (dim < 0 || index_dim < 0) return fail(ORR_EINVAL, "orr_merge_candidates: negative dimension");
     const bool use_cos = dim > 0 && dim == index_dim;
     if (use_cos && !q_host) return fail(ORR_EINVAL, "orr_merge_candidates: q_host is required with dim %d", dim);
-    return merge_impl(n_shards, B, kprime, all, dim, use_cos, q_host, query_term_off, now_ticks, topk, out_rows,
+    return merge_impl(n_shards, B, kprime, all, dim, use_cos, q_host, nullptr, query_term_off, now_ticks, topk, out_rows,
                       out_scores, out_counts, out_uncertified);
 }
 
@@ -1523,8 +1553,8 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
             recs = copied.data();
         }
         int32_t unc = 0;
-        ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, query_term_off, now_ticks,
-                           topk, out_rows, out_scores, out_counts, &unc));
+        ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, use_cos ? idx->h_norm_a.data() : nullptr,
+                           query_term_off, now_ticks, topk, out_rows, out_scores, out_counts, &unc));
         if (unc == 0) return ORR_OK;
         if (a.used_fused && !a.no_fuse) { a.no_fuse = true; continue; }   // a buffer overflow or a tie at the cut: unfused pass
         if (a.used_mfma) { a.force_exact = true; continue; }        // then the exact pass, same k'
