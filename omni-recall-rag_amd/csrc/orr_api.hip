@@ -1476,20 +1476,42 @@ int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate 
         exact_norms(q_host, B, dim, own_norms.data());
         norms = own_norms.data();
     }
-    std::vector<const orr_candidate *> recs((size_t)n_shards);
-    for (int32_t b = 0; b < B; ++b) {
-        for (int32_t sidx = 0; sidx < n_shards; ++sidx)
-            recs[sidx] = all + ((size_t)sidx * B + b) * ((size_t)kprime + 1);
-        const double norm_a = use_cos ? norms[b] : 0.0;
-        const int32_t n_terms = (int32_t)(query_term_off[b + 1] - query_term_off[b]);
-        bool cert = false;
-        int err = ORR_OK;
-        for (int32_t i = 0; i < take; ++i) { out_rows[(size_t)b * take + i] = -1; out_scores[(size_t)b * take + i] = 0.0; }
-        const int32_t cnt = finish_query(recs.data(), n_shards, kprime, use_cos, norm_a, n_terms, now_ticks, topk,
-                                         out_rows + (size_t)b * take, out_scores + (size_t)b * take, &cert, &err);
-        if (err != ORR_OK) return err;
-        if (out_counts) out_counts[b] = cnt;
-        if (!cert) ++unc;
+    // queries are independent: large merges (many queries x many shards) are split over a few host threads
+    auto work = [&](int32_t b_begin, int32_t b_end, int32_t *unc_out, int *err_out) {
+        std::vector<const orr_candidate *> recs((size_t)n_shards);
+        for (int32_t b = b_begin; b < b_end; ++b) {
+            for (int32_t sidx = 0; sidx < n_shards; ++sidx)
+                recs[sidx] = all + ((size_t)sidx * B + b) * ((size_t)kprime + 1);
+            const double norm_a = use_cos ? norms[b] : 0.0;
+            const int32_t n_terms = (int32_t)(query_term_off[b + 1] - query_term_off[b]);
+            bool cert = false;
+            int err = ORR_OK;
+            for (int32_t i = 0; i < take; ++i) { out_rows[(size_t)b * take + i] = -1; out_scores[(size_t)b * take + i] = 0.0; }
+            const int32_t cnt = finish_query(recs.data(), n_shards, kprime, use_cos, norm_a, n_terms, now_ticks, topk,
+                                             out_rows + (size_t)b * take, out_scores + (size_t)b * take, &cert, &err);
+            if (err != ORR_OK) { *err_out = err; return; }
+            if (out_counts) out_counts[b] = cnt;
+            if (!cert) ++*unc_out;
+        }
+    };
+    const int64_t n_records = (int64_t)B * n_shards * kprime;
+    int n_thr = n_records >= 16384 ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (n_thr > B) n_thr = B;
+    std::vector<int32_t> t_unc((size_t)n_thr, 0);
+    std::vector<int> t_err((size_t)n_thr, ORR_OK);
+    if (n_thr == 1) {
+        work(0, B, &t_unc[0], &t_err[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_thr; ++t)
+            th.emplace_back(work, (int32_t)((int64_t)B * t / n_thr), (int32_t)((int64_t)B * (t + 1) / n_thr), &t_unc[(size_t)t], &t_err[(size_t)t]);
+        work(0, (int32_t)((int64_t)B / n_thr), &t_unc[0], &t_err[0]);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < n_thr; ++t) {
+        if (t_err[(size_t)t] != ORR_OK)
+            return t == 0 ? t_err[0] : fail(t_err[(size_t)t], "orr_merge_candidates: a shard's records are malformed");
+        unc += t_unc[(size_t)t];
     }
     if (out_uncertified) *out_uncertified = unc;
     return ORR_OK;

@@ -30,8 +30,29 @@ def _ptr(x) -> Optional[int]:
     return x.ctypes.data
 
 
-def pack_terms(queries_terms: Sequence[Sequence[bytes]]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+class PackedTerms:
+    """(terms_utf8, term_off, query_term_off) already in the ABI's form; accepted wherever a list of
+    per-query term lists is (saves re-packing the same batch for several calls).  Indexing gives one
+    query's terms as a list of bytes, like the list form."""
+
+    def __init__(self, arrays):
+        self.arrays = tuple(arrays)
+
+    def __len__(self):
+        return int(self.arrays[2].shape[0]) - 1
+
+    def __getitem__(self, b: int):
+        pool, toff, qoff = self.arrays
+        return [bytes(pool[int(toff[i]):int(toff[i + 1])]) for i in range(int(qoff[b]), int(qoff[b + 1]))]
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self)))
+
+
+def pack_terms(queries_terms) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """[[term bytes]] per query -> (terms_utf8, term_off, query_term_off) of the ABI."""
+    if isinstance(queries_terms, PackedTerms):
+        return queries_terms.arrays
     pool = bytearray()
     term_off = [0]
     qoff = [0]

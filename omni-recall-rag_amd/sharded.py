@@ -15,31 +15,60 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .index import CAND_DTYPE, RecallIndex, merge_candidates
+from .index import CAND_DTYPE, PackedTerms, RecallIndex, merge_candidates, pack_terms
 
 TERM_SLOT = 256        # bytes reserved per query for its packed terms
 
 
-def _pack_terms_fixed(terms: Sequence[bytes]) -> np.ndarray:
-    out = bytearray([len(terms)])
-    for t in terms:
-        if len(t) > 255:
-            raise ValueError("term longer than 255 bytes")
-        out.append(len(t))
-        out += t
-    if len(out) > TERM_SLOT or len(terms) > 255:
+def _slots_from_packed(pool: np.ndarray, toff: np.ndarray, qoff: np.ndarray) -> np.ndarray:
+    """ABI term arrays -> one TERM_SLOT-byte slot per query: [n][len_0 .. len_{n-1}][bytes...], zero padded.
+    Vectorised: a batch of 1024 queries costs a fraction of a millisecond."""
+    B = int(qoff.shape[0]) - 1
+    slots = np.zeros((B, TERM_SLOT), dtype=np.uint8)
+    if B == 0:
+        return slots
+    toff = toff.astype(np.int64)
+    qoff = qoff.astype(np.int64)
+    lens = np.diff(toff)                                    # per term
+    n = np.diff(qoff)                                       # terms per query
+    qbytes = toff[qoff[1:]] - toff[qoff[:-1]]               # term bytes per query
+    if lens.size and int(lens.max()) > 255:
+        raise ValueError("term longer than 255 bytes")
+    if int(n.max()) > 255 or int((1 + n + qbytes).max()) > TERM_SLOT:
         raise ValueError("query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
-    out += bytes(TERM_SLOT - len(out))
-    return np.frombuffer(bytes(out), dtype=np.uint8)
+    slots[:, 0] = n
+    tq = np.repeat(np.arange(B), n)                         # query of each term
+    slots[tq, 1 + np.arange(lens.size) - qoff[tq]] = lens
+    total = int(toff[-1])
+    bq = np.repeat(np.arange(B), qbytes)                    # query of each term byte
+    slots[bq, 1 + n[bq] + np.arange(total) - toff[qoff[bq]]] = pool[:total]
+    return slots
+
+
+def _packed_from_slots(slots: np.ndarray) -> PackedTerms:
+    """The inverse, for all gathered queries at once."""
+    B = int(slots.shape[0])
+    n = slots[:, 0].astype(np.int64)
+    col = np.arange(TERM_SLOT, dtype=np.int64)[None, :]
+    len_mask = (col >= 1) & (col < 1 + n[:, None])
+    lens = slots[len_mask].astype(np.int64)                 # row-major: query order, then term order
+    qoff = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(n, out=qoff[1:])
+    toff = np.zeros(lens.size + 1, dtype=np.int64)
+    np.cumsum(lens, out=toff[1:])
+    qbytes = toff[qoff[1:]] - toff[qoff[:-1]]
+    byte_mask = (col >= 1 + n[:, None]) & (col < 1 + n[:, None] + qbytes[:, None])
+    pool = np.concatenate([slots[byte_mask], np.zeros(1, dtype=np.uint8)])
+    return PackedTerms((np.ascontiguousarray(pool), toff.astype(np.uint32), qoff.astype(np.uint32)))
+
+
+def _pack_terms_fixed(terms: Sequence[bytes]) -> np.ndarray:
+    """One query's slot (kept for tests and small callers)."""
+    return _slots_from_packed(*pack_terms([terms]))[0]
 
 
 def _unpack_terms_fixed(slot: np.ndarray) -> List[bytes]:
-    n, p, out = int(slot[0]), 1, []
-    for _ in range(n):
-        ln = int(slot[p])
-        out.append(bytes(slot[p + 1:p + 1 + ln]))
-        p += 1 + ln
-    return out
+    return _packed_from_slots(slot[None, :])[0]
 
 
 class ShardedRecallSearch:
@@ -71,7 +100,7 @@ class ShardedRecallSearch:
         send = torch.empty((B_local, slot), dtype=torch.uint8, device=self.device)
         if dim:
             send[:, :vec_bytes] = q_local.contiguous().view(torch.uint8).reshape(B_local, vec_bytes)
-        tslots = np.stack([_pack_terms_fixed(t) for t in terms_local])
+        tslots = _slots_from_packed(*pack_terms(terms_local))
         send[:, vec_bytes:] = torch.from_numpy(tslots).to(self.device, non_blocking=True)
         if W > 1:
             allq = torch.empty((W * B_local, slot), dtype=torch.uint8, device=self.device)
@@ -82,7 +111,7 @@ class ShardedRecallSearch:
         q_all = allq[:, :vec_bytes].contiguous().view(torch.float32).reshape(B, dim) if dim else None
         allq_host = allq.cpu().numpy()              # ONE download: vectors (for the exact normA) + terms
         q_host = np.ascontiguousarray(allq_host[:, :vec_bytes]).view(np.float32).reshape(B, dim) if dim else None
-        terms_all = [_unpack_terms_fixed(allq_host[b, vec_bytes:]) for b in range(B)]
+        terms_all = _packed_from_slots(allq_host[:, vec_bytes:])   # ABI form, packed once for both calls below
 
         while True:
             # ---- local scoring of every query against this shard
