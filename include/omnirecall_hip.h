@@ -191,7 +191,8 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
- *   "two_stage"      0/1/2 (default 1): the same batches take ONE plain-bf16 product over all rows
+ *   "two_stage"      0/1/2 (default 1): batches of >= 5 queries over >= 196,608 rows take ONE plain-bf16
+ *                    product over all rows
  *                    (bound 2^-7 |q||e| on the dot), keep every (query,row) pair that could reach a lower
  *                    bound of the query's k-th best score, and re-score those in the reference arithmetic on
  *                    the device.  1: the product reads a bf16 shadow copy of the embeddings

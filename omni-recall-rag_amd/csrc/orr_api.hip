@@ -1038,10 +1038,12 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
             d_dotf = idx->ws_dotf.as<float>();
         }
-        // 33..64 queries: two streaming launches (5.2 ms at 1M rows) lose to the two-stage pass (3.5 ms) where it applies
+        // Where the two-stage pass applies it wins from the first MFMA batch on (1M x 3072 rows: 8 queries 2.19 ms
+        // against 2.35 ms streaming, 32 queries 2.28 against 3.07, 64 queries 2.4 against 6.3); ORR_TS_MIN_BATCH moves that
         const bool ts_eligible = idx->opt_two_stage != 0 && !a.no_fuse && (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 &&
                                  std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
-        if (B <= 32 || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form, 32 queries per launch (two launches at most)
+        static const int ts_min_batch = [] { const char *e = getenv("ORR_TS_MIN_BATCH"); return e ? atoi(e) : 5; }();
+        if (B < ts_min_batch || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form, 32 queries per launch (two launches at most)
             for (int32_t b0 = 0; b0 < B; b0 += 32) {
                 const int32_t nq = std::min<int32_t>(32, B - b0);
                 Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);

@@ -99,6 +99,17 @@ def test_batched_passes_equal_the_exact_pass_at_1m(big):
             assert ("screen_bf16_fused" if mode == 1 else "gemm_dot_bf16x1_fused") in stats
             assert stats["gemm_dot_bf16x3"]["launches"] == 1          # certified without a repeat
     idx.set_option("two_stage", 1)
+    # small MFMA batches take the same route (the streaming GEMV is the fallback without the two-stage pass)
+    for nb in (5, 8, 33):
+        idx.set_profiling(True)
+        r, s, c = idx.search(q[:nb], terms[:nb], syn.NOW_TICKS, 10, candidate_limit=n)
+        assert "screen_bf16_fused" in idx.kernel_stats()
+        idx.set_profiling(False)
+        assert np.array_equal(r, exact_rows[:nb]) and np.array_equal(s, exact_scores[:nb]), nb
+    idx.set_option("two_stage", 0)
+    r, s, c = idx.search(q[:24], terms[:24], syn.NOW_TICKS, 10, candidate_limit=n)      # streaming GEMV
+    assert np.array_equal(r, exact_rows[:24]) and np.array_equal(s, exact_scores[:24])
+    idx.set_option("two_stage", 1)
     # a candidate_limit that cuts the corpus goes through the same pass on the prefix
     m = 600_000
     r, s, c = idx.search(q[:96], terms[:96], syn.NOW_TICKS, 10, candidate_limit=m)
