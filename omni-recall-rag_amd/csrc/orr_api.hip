@@ -977,9 +977,20 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     // up; below it the HBM-bound exact kernel is as fast and needs no second pass.
     static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
     const bool use_mfma = use_cos && !a.force_exact && B >= mfma_min_batch && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
-    a.used_mfma = use_mfma;
+    // 1..4 queries: the exact kernel reads all 12 KiB of every row; with the bf16 shadow in place the same
+    // two-stage idea applies without the matrix core: exact dots over a sampled prefix give the floor, a
+    // stream over the shadow (half the bytes) keeps what can reach it, the survivors are re-scored exactly.
+    bool ts_small = false;
+    if (use_cos && !use_mfma && !a.force_exact && !a.no_fuse && idx->opt_two_stage == 1 && idx->dim % 64 == 0 &&
+        kprime <= orr::kSelWidth && (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
+        B <= 4) {
+        ORR_TRY(ensure_shadow(idx));
+        ts_small = idx->shadow_ready;
+    }
+    const bool approx_pass = use_mfma || ts_small;       // records carry no dot yet: K6 fills it in, exactly
+    a.used_mfma = approx_pass;
     a.used_fused = false;
-    const bool direct_host = host_records && !use_mfma && rec_bytes <= (256u << 10);
+    const bool direct_host = host_records && !approx_pass && rec_bytes <= (256u << 10);
     orr_candidate *d_cand = nullptr;
     if (direct_host) {
         ORR_TRY(idx->pin_cand.reserve(rec_bytes));
@@ -1084,6 +1095,20 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const double eps_cos = bf16_split ? 3.1 * u16 + 3.06 * (double)idx->dim * u23
                                           : (2.0 * (double)idx->dim + 2.0) * u23;
         approx_eps = 0.7 * 1.01 * eps_cos + 1e-12;
+    } else if (ts_small) {
+        const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
+        two_stage = true;
+        fused_sample_seg = std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16));
+        dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
+        ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)dotf_rows));
+        d_dot = idx->ws_dot.as<double>();
+        {
+            Timed t(idx, "dot_exact_prefix", 4.0 * (double)dotf_rows * idx->dim + 4.0 * B * idx->dim + 8.0 * B * (double)dotf_rows);
+            HIP_TRY(orr::launch_dot_exact(idx->d_emb, dotf_rows, idx->dim, d_q, B, false, d_dot, dotf_rows, s));
+        }
+        ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
+        HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+        approx_eps = 1e-12;                                  // the prefix scores are exact up to the selection form's few ulp
     } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
         d_dot = idx->ws_dot.as<double>();
@@ -1190,7 +1215,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     }
 
     // ---- per-query constants (exact normA needs the vectors on the host)
-    const bool batched_score = B >= 4 && kprime <= orr::kSelWidth;     // per-row pieces once per batch
+    const bool batched_score = (B >= 4 || ts_small) && kprime <= orr::kSelWidth;     // per-row pieces once per batch
     if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
     ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
@@ -1238,15 +1263,16 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             d_tau = idx->ws_tau.as<unsigned long long>();
             {
                 Timed t(idx, "fuse_select", (double)B * (double)dotf_rows * 28.0);
-                HIP_TRY(orr::launch_fuse_select(nullptr, d_dotf, dotf_rows, idx->d_norm_b, idx->d_created, d_rowc, kw,
-                                                idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, dotf_rows, B, 0, fused_sample_seg,
-                                                nullptr, idx->ws_sel.as<orr::SelEntry>(), lists_total, s));
+                HIP_TRY(orr::launch_fuse_select(ts_small ? d_dot : nullptr, ts_small ? nullptr : d_dotf, dotf_rows, idx->d_norm_b,
+                                                idx->d_created, d_rowc, kw, idx->ws_qc.as<orr::QueryConst>(), a.now_ticks,
+                                                dotf_rows, B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
+                                                lists_total, s));
             }
             ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * (size_t)B));
             orr::FusedEpilogue epi;
             epi.count_planes = nullptr;
             epi.plane_stride = (n + 63) / 64 * 64;
-            if (kw.bitmaps) {
+            if (kw.bitmaps && !ts_small) {
                 Timed t(idx, "count_planes", 4.0 * orr::kCountPlanes * (double)((B + 31) / 32) * (double)n);
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
                 HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s));
@@ -1275,7 +1301,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                        idx->ws_fqf.as<float4>(), s));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (idx->opt_two_stage == 1) ORR_TRY(ensure_shadow(idx));
-                if (idx->opt_two_stage == 1 && idx->shadow_ready) {
+                if (ts_small) {
+                    Timed t(idx, "screen_gemv_bf16", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
+                    HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, n, idx->dim, epi, s));
+                } else if (idx->opt_two_stage == 1 && idx->shadow_ready) {
                     ORR_TRY(idx->ws_qtiled.reserve(orr::bf16_tiled_bytes(B, idx->dim)));
                     HIP_TRY(orr::launch_bf16_tiled(d_q, B, idx->dim, idx->ws_qtiled.p, s));
                     Timed t(idx, "screen_bf16_fused", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
@@ -1353,7 +1382,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                              use_mfma ? 0 : 1, approx_eps, nullptr, nullptr, 0u, nullptr, d_cand, s));
         }
         }
-        if (use_mfma) {   // K6: the survivors' dots again, now in the reference's own arithmetic
+        if (approx_pass) {   // K6: the survivors' dots again, now in the reference's own arithmetic
             Timed t(idx, "rescore_exact", (double)B * kprime * 4.0 * idx->dim);
             HIP_TRY(orr::launch_rescore_exact(idx->d_emb, idx->dim, d_q, B, kprime, idx->row_base, d_cand, s));
         }

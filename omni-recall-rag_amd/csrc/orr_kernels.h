@@ -144,6 +144,9 @@ size_t bf16_tiled_bytes(int64_t n_rows, int32_t D);
 hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *out, hipStream_t s);
 hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shadow, int64_t row_first, int64_t n_rows,
                               int32_t D, float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s);
+// K2g: the screening pass for 1..4 queries as a stream over the tiled shadow (no matrix core).
+hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_shadow, int64_t n_rows, int32_t D,
+                                   const FusedEpilogue &epi, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
 hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
                                   unsigned long long *floor_key, double *L_out, hipStream_t s);

@@ -175,6 +175,96 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     }
 }
 
+// K2g: the same screening pass for 1..4 queries -- no matrix core, a pure stream over the tiled shadow.
+// Work unit = half a row tile (128 rows x D): per K-tile its 8 KiB are eight 1 KiB wave loads, lane l
+// always holding chunk c = (l & 3) ^ ((l >> 4) & 3) of rows 16 j + (l >> 2), j = 0..7 (the swizzle of the
+// stored layout does not depend on j), so one 16-byte read of the query's hi half from LDS serves all
+// eight rows.  v_dot2c_f32_bf16 accumulates in fp32 (exact products, 3072 additions: the bound of the
+// GEMM form holds, its order is not assumed).  Two register stages keep 16 KiB per wave in flight.
+// Epilogue: quad reduction, then lane (quad, s) scores rows j = s and j = s + 4 in fp64 against the floor.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+template <int NQ>
+__global__ __launch_bounds__(256, 2) void screen_gemv_bf16_kernel(const __bf16 *__restrict__ q_hi, int32_t D,
+                                                                  const __bf16 *__restrict__ Eh, int64_t n_units,
+                                                                  int64_t n_rows, FusedEpilogue epi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lq[];     // [NQ][D] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid * 8; i < NQ * D; i += 256 * 8)
+        *reinterpret_cast<bf16x8 *>(lq + (size_t)i * 2) = *reinterpret_cast<const bf16x8 *>(q_hi + i);
+    __syncthreads();
+    const int c = (lane & 3) ^ ((lane >> 4) & 3);
+    const int KT = D / kScBK;
+    for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < n_units; u += (int64_t)gridDim.x * 4) {
+        const __bf16 *base = Eh + ((u >> 1) * KT) * (int64_t)(kScImage / 2) + (u & 1) * (kScImage / 4) + lane * 8;
+        float acc[NQ][8];
+#pragma unroll
+        for (int b = 0; b < NQ; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[b][j] = 0.f;
+        bf16x8 s0[8], s1[8];
+        auto load = [&](bf16x8 (&st)[8], int kt) {
+            const __bf16 *p = base + (int64_t)kt * (kScImage / 2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(p + j * 512));
+        };
+        auto compute = [&](const bf16x8 (&st)[8], int kt) {
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) {
+                const bf16x8 qv = *reinterpret_cast<const bf16x8 *>(lq + ((size_t)b * D + kt * kScBK + c * 8) * 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2v ev = {st[j][2 * e], st[j][2 * e + 1]};
+                        const bf16x2v qq = {qv[2 * e], qv[2 * e + 1]};
+                        acc[b][j] = __builtin_amdgcn_fdot2_f32_bf16(ev, qq, acc[b][j], false);
+                    }
+                }
+            }
+        };
+        load(s0, 0);
+        for (int kt = 0; kt < KT; kt += 2) {                                // KT = D / 32 is even
+            load(s1, kt + 1);
+            compute(s0, kt);
+            load(s0, kt + 2 < KT ? kt + 2 : KT - 1);                         // clamped, never branched around
+            compute(s1, kt + 1);
+        }
+        // quad reduction: the four lanes of a quad hold the four chunks of the same rows
+#pragma unroll
+        for (int b = 0; b < NQ; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[b][j] += __shfl_xor(acc[b][j], 1, 64);
+                acc[b][j] += __shfl_xor(acc[b][j], 2, 64);
+            }
+        const int sl = lane & 3;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int64_t row = (u >> 1) * kScBN + (u & 1) * 128 + 16 * (jj * 4 + sl) + (lane >> 2);
+            if (row >= n_rows) continue;
+            const double2 rc = epi.rowc[row];
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) {
+                const float a = sl == 0 ? acc[b][jj * 4] : sl == 1 ? acc[b][jj * 4 + 1] : sl == 2 ? acc[b][jj * 4 + 2] : acc[b][jj * 4 + 3];
+                const QueryConst qc = epi.qc[b];
+                const uint32_t mm = qc.n_terms > 0 ? kw_matches(epi.kw, b, (uint32_t)row) : 0u;
+                unsigned long long key = score_key(fused_score_fast((double)a, rc.x, rc.y, mm, qc));
+                if (!(__builtin_fabsf(a) <= 3.4028234663852886e38f)) key = ~0ull;   // never dropped: re-scored exactly later
+                if (key > epi.tau[b]) {
+                    const uint32_t slot = atomicAdd(&epi.cnt[b], 1u);
+                    if (slot < epi.cap) {
+                        SelEntry en;
+                        en.key = key; en.pos = (uint32_t)row; en.pad = 0;
+                        epi.buf[(int64_t)b * epi.cap + slot] = en;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Tiled, pre-swizzled bf16 image of a row-major fp32 matrix X[n_rows][D] (see the header): output
 // chunk o (16 bytes) = 8 consecutive k of one row.  rows_padded = n_tiles * 256.
 __global__ __launch_bounds__(256) void bf16_tiled_kernel(const float *__restrict__ X, int64_t n_rows, int32_t D, int64_t n_chunks,
@@ -219,6 +309,27 @@ hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *ou
     const int64_t n_chunks = (int64_t)(bf16_tiled_bytes(n_rows, D) / 16);
     const int64_t blocks = std::min<int64_t>((n_chunks + 255) / 256, 65536);
     hipLaunchKernelGGL(bf16_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, n_rows, D, n_chunks, static_cast<__bf16 *>(out));
+    return hipGetLastError();
+}
+
+// The screening pass for B <= 4 queries: q_hi is the linear [B][D] bf16 image (hi halves of
+// launch_split_queries), the fused epilogue is mandatory.
+hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_shadow, int64_t n_rows, int32_t D,
+                                   const FusedEpilogue &epi, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (B > 4 || D <= 0 || D % 64 != 0) return hipErrorInvalidValue;
+    const int64_t n_units = ((n_rows + kScBN - 1) / kScBN) * 2;
+    const int64_t blocks = std::min<int64_t>((n_units + 3) / 4, 512);
+    const size_t lds = sizeof(uint16_t) * (size_t)B * (size_t)D;
+    if (lds > 65536) return hipErrorInvalidValue;
+    const __bf16 *qh = static_cast<const __bf16 *>(q_hi), *eh = static_cast<const __bf16 *>(e_shadow);
+    switch (B) {
+    case 1: hipLaunchKernelGGL(screen_gemv_bf16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
+    case 2: hipLaunchKernelGGL(screen_gemv_bf16_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
+    case 3: hipLaunchKernelGGL(screen_gemv_bf16_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
+    default: hipLaunchKernelGGL(screen_gemv_bf16_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
+    }
     return hipGetLastError();
 }
 

@@ -429,8 +429,20 @@ def test_two_stage_batched_pass_matches_oracle():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow), (topk, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (topk, b)
-    # the sharded entry point takes the same route (floor from the k'-th best) and merges exactly
+    # 1..4 queries: exact dots over the prefix give the floor, the shadow is streamed without the matrix core
     idx.set_option("two_stage", 1)
+    for b0, nb in ((0, 1), (2, 1), (3, 1), (0, 4), (4, 3), (100, 2)):
+        idx.set_profiling(True)
+        rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
+        assert "screen_gemv_bf16" in idx.kernel_stats()
+        idx.set_profiling(False)
+        for b in range(nb):
+            orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
+            assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (b0, b)
+    rows, scores, counts = idx.search(q_over[5:6], terms[5:6], NOW, 10, candidate_limit=n)     # buffer overflow -> exact pass
+    orow, osc, _ = corpus.search(q_over[5], texts[5], NOW, 10, candidate_limit=n, threads=8)
+    assert list(rows[0, :counts[0]]) == list(orow) and np.array_equal(scores[0, :counts[0]], osc)
+    # the sharded entry point takes the same route (floor from the k'-th best) and merges exactly
     kprime = 32
     recs = idx.search_shard(qs, terms, NOW, kprime, candidate_limit=n)
     mrows, mscores, mcounts, unc = P.merge_candidates(recs[None], dim, qs, terms, NOW, 10)

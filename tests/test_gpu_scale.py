@@ -83,6 +83,7 @@ def test_batched_passes_equal_the_exact_pass_at_1m(big):
     terms = [P.text.query_terms(t) for t in texts]
     exact_rows = np.empty((B, 10), dtype=np.int64)
     exact_scores = np.empty((B, 10), dtype=np.float64)
+    idx.set_option("two_stage", 0)                          # baseline: the reference-arithmetic kernel over every row
     for b0 in range(0, B, 4):
         r, s, c = idx.search(q[b0:b0 + 4], terms[b0:b0 + 4], syn.NOW_TICKS, 10, candidate_limit=n)
         assert (c == 10).all()
@@ -99,11 +100,11 @@ def test_batched_passes_equal_the_exact_pass_at_1m(big):
             assert ("screen_bf16_fused" if mode == 1 else "gemm_dot_bf16x1_fused") in stats
             assert stats["gemm_dot_bf16x3"]["launches"] == 1          # certified without a repeat
     idx.set_option("two_stage", 1)
-    # small MFMA batches take the same route (the streaming GEMV is the fallback without the two-stage pass)
-    for nb in (5, 8, 33):
+    # small batches take the same route: 1..4 queries stream the shadow (no matrix core), 5+ use the GEMM
+    for nb in (1, 2, 3, 4, 5, 8, 33):
         idx.set_profiling(True)
         r, s, c = idx.search(q[:nb], terms[:nb], syn.NOW_TICKS, 10, candidate_limit=n)
-        assert "screen_bf16_fused" in idx.kernel_stats()
+        assert ("screen_gemv_bf16" if nb <= 4 else "screen_bf16_fused") in idx.kernel_stats()
         idx.set_profiling(False)
         assert np.array_equal(r, exact_rows[:nb]) and np.array_equal(s, exact_scores[:nb]), nb
     idx.set_option("two_stage", 0)
