@@ -3,7 +3,10 @@
 
 Workload (BASELINE.json configs[1], "C2"): 1M chunks x 3072-d fp32 PER GPU, top-k=10,
 full hybrid score (cosine + keyword + recency fused 0.7/0.2/0.1), candidate_limit =
-whole corpus.  A step is one pass of the hot path over one batch: every rank
+whole corpus.  Results are exact (reference arithmetic); by default the library screens the
+corpus through its bf16 shadow and re-scores the survivors from the fp32 master,
+so the dominant kernel streams 2*N*D bytes; `--set-option two_stage=0` restores the exact kernel
+over all 4*N*D bytes.  A step is one pass of the hot path over one batch: every rank
 originates ONE query; with N ranks the corpus is N x 1M rows, row-sharded, and each
 query is scored against ALL shards (queries all-gathered, per-shard top-k' records
 all-gathered over RCCL, exact host finish).  Weak scaling: per-GPU rows are fixed,
@@ -175,12 +178,15 @@ def main():
         # HBM bytes per dot_exact launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload shape.
         traffic = None
+        traffic_gemv = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if os.path.exists(pmc_path) and (rows, dim, B_local) == (1_000_000, 3072, 1):
             with open(pmc_path) as f:
                 for kname, kv in json.load(f)["kernels"].items():
-                    if kname.startswith("orr::dot_exact_tiled<1, false") and "hbm_bytes_per_launch_corrected" in kv:
+                    if kname == "orr::dot_exact_tiled<1, false, true, true>" and "hbm_bytes_per_launch_corrected" in kv:
                         traffic = kv["hbm_bytes_per_launch_corrected"]
+                    if kname.startswith("orr::screen_gemv_bf16_kernel<1>") and "hbm_bytes_per_launch_corrected" in kv:
+                        traffic_gemv = kv["hbm_bytes_per_launch_corrected"]
         if "screen_gemv_bf16" in stats and stats["screen_gemv_bf16"]["launches"]:
             # 1..4 queries per step with the bf16 shadow: the dominant kernel streams the shadow (2*N*D bytes)
             sg = stats["screen_gemv_bf16"]
@@ -188,7 +194,8 @@ def main():
             bytes_per_launch = sg["algo_bytes"] / sg["launches"]
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "screen_gemv_bf16", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_gemv,
+                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic_gemv else None,
                         "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
         elif dom["launches"]:
             avg_ms = dom["total_ms"] / dom["launches"]
