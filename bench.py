@@ -46,8 +46,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1, help="queries originated per rank per step")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=131072)
-    ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    ap.add_argument("--cpu-sample-rows", type=int, default=262144)
+    ap.add_argument("--cpu-sample-queries", type=int, default=32)
     ap.add_argument("--no-terms", action="store_true", help="diagnostic: queries without keyword terms")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="orr_index_set_option on the shard before the run (e.g. two_stage=1)")
@@ -70,18 +70,19 @@ def build_shard(P, syn, torch, rank, rows, dim, n_total, dev, options=()):
     return idx
 
 
-def cpu_baseline(P, syn, args, n_total):
+def cpu_baseline(P, syn, args, n_total, torch, dev):
     """The reference-faithful oracle (kind "port") timed on the host cores over a bounded sample."""
     import numpy as np
     from oracle import oracle_py as orc
     m = min(args.cpu_sample_rows, args.rows_per_gpu)
     nq = args.cpu_sample_queries
     cores = max(1, min(os.cpu_count() or 1, 64))
-    emb = syn.embeddings(0, m, args.dim).numpy()
-    created = syn.created_ticks(0, m, n_total).numpy()
-    pool, off = syn.contents(0, m)
-    corpus = orc.OracleCorpus(emb, created, (pool.numpy(), off.numpy()))
-    qs = syn.query_vectors(0, nq, args.dim, n_total).numpy()
+    # the sample is generated on the GPU (same deterministic generator) and copied to the host
+    emb = torch.cat([syn.embeddings(r0, min(32768, m - r0), args.dim, dev).cpu() for r0 in range(0, m, 32768)]).numpy()
+    created = syn.created_ticks(0, m, n_total, dev).cpu().numpy()
+    pool, off = syn.contents(0, m, dev)
+    corpus = orc.OracleCorpus(emb, created, (pool.cpu().numpy(), off.cpu().numpy()))
+    qs = syn.query_vectors(0, nq, args.dim, n_total, dev).cpu().numpy()
     texts = syn.query_texts(0, nq, n_total)
     t0 = time.perf_counter()
     for b in range(nq):
@@ -232,7 +233,7 @@ def main():
                         for n, v in stats.items()},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, syn, args, n_total)
+            out["cpu_baseline"] = cpu_baseline(P, syn, args, n_total, torch, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
