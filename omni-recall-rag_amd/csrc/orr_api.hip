@@ -162,7 +162,7 @@ struct orr_index {
     bool shadow_ready = false, shadow_failed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -446,7 +446,7 @@ void orr_index_destroy(orr_index *idx)
     if (idx->d_post_off) (void)hipFree(idx->d_post_off);
     if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
-                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -1043,6 +1043,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     bool bf16_split = false;
     int32_t fused_sample_seg = 0;      // > 0: fused epilogue behind a sampled prefix of that many segments
     bool two_stage = false;            // plain-bf16 first stage over all rows + exact second stage
+    bool records_have_dots = false;    // two-stage: exact dots copied from the survivors' buffer
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
         if (B <= 64 || getenv("ORR_GEMM_KIND")) {
@@ -1315,8 +1316,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 }
                 {
                     Timed t(idx, "rescore_buffer_exact", 0.0);
+                    ORR_TRY(idx->ws_fdot.reserve(sizeof(double) * (size_t)B * kCap));
                     HIP_TRY(orr::launch_rescore_buffer_exact(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, kw,
-                                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf, s));
+                                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf,
+                                                             idx->ws_fdot.as<double>(), s));
                 }
                 {
                     Timed t(idx, "buffer_to_lists", 0.0);
@@ -1327,6 +1330,12 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                     HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), buf_lists, B, kprime, n, idx->row_base,
                                                      nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
                                                      0, 0.0, nullptr, epi.cnt, kCap, idx->ws_tsL.as<double>(), d_cand, s));
+                }
+                {   // the records' exact dots come out of the buffer: no second K6 pass
+                    Timed t(idx, "records_dot_from_buffer", 0.0);
+                    HIP_TRY(orr::launch_records_dot_from_buffer(epi.buf, idx->ws_fdot.as<double>(), epi.cnt, kCap, B, kprime, idx->row_base,
+                                                                d_cand, s));
+                    records_have_dots = true;
                 }
             } else {
             {
@@ -1382,7 +1391,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                              use_mfma ? 0 : 1, approx_eps, nullptr, nullptr, 0u, nullptr, d_cand, s));
         }
         }
-        if (approx_pass) {   // K6: the survivors' dots again, now in the reference's own arithmetic
+        if (approx_pass && !records_have_dots) {   // K6: the survivors' dots again, now in the reference's own arithmetic
             Timed t(idx, "rescore_exact", (double)B * kprime * 4.0 * idx->dim);
             HIP_TRY(orr::launch_rescore_exact(idx->d_emb, idx->dim, d_q, B, kprime, idx->row_base, d_cand, s));
         }

@@ -508,6 +508,57 @@ hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float
     return launch_bf16x3_variant<2, true, false, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
 }
 
+// Reference-order fp64 dots (RecallSearchService.cs:77-82) of one query against up to 64 gathered rows,
+// one row per lane: the rows' 64-column pieces go through a wave-private XOR-swizzled LDS tile (coalesced
+// 256-byte reads per row piece, conflict-free ds_read_b128 per lane), the next piece already requested
+// while the current one is summed.  (Two pieces ahead needs 170 VGPRs and measured slower at every batch
+// size: with many waves the occupancy matters more, with few the serial fp64 chain sets the pace.)
+// rows[] (LDS, 64 entries, -1 = none) must be visible to the wave.  D % 64 == 0.
+__device__ __forceinline__ double exact_dot_of_gathered_rows(const float *__restrict__ E, int32_t D, const float *__restrict__ q,
+                                                             const int64_t *rows, float *tile, int lane)
+{
+    const int ld_row = lane >> 4, ld_ch = lane & 15;
+    double acc = 0.0;
+    float4 stage[16];
+    auto load_stage = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int64_t row = rows[it * 4 + ld_row];
+            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0) stage[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
+        }
+    };
+    load_stage(0);
+    for (int c0 = 0; c0 < D; c0 += 64) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + ld_row;
+            *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
+        }
+        if (c0 + 64 < D) load_stage(c0 + 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 e = *reinterpret_cast<const float4 *>(tile + lane * 64 + ((j ^ (lane & 15)) << 2));
+            const float *qp = q + c0 + j * 4;
+            float p0 = qp[0] * e.x;
+            acc += (double)p0;
+            float p1 = qp[1] * e.y;
+            acc += (double)p1;
+            float p2 = qp[2] * e.z;
+            acc += (double)p2;
+            float p3 = qp[3] * e.w;
+            acc += (double)p3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return acc;
+}
+
 // Two-stage pass, floor: with s_k = the k-th best split-pass score of the sampled prefix,
 //   L = s_k - eps3           a lower bound of the exact k-th best score of the prefix, hence of the corpus
 //   F = L - eps1 - margin    a row whose plain-bf16 score is below F has an exact score below L
@@ -549,7 +600,7 @@ __global__ __launch_bounds__(64) void rescore_buffer_exact_kernel(const float *_
                                                                   const int64_t *__restrict__ created, KwView kw,
                                                                   const QueryConst *__restrict__ qcs, int64_t now_ticks,
                                                                   const uint32_t *__restrict__ cnt, uint32_t cap,
-                                                                  SelEntry *__restrict__ buf)
+                                                                  SelEntry *__restrict__ buf, double *__restrict__ buf_dot)
 {
     __shared__ __attribute__((aligned(16))) float tile[64 * 64];
     __shared__ int64_t rows[64];
@@ -564,63 +615,61 @@ __global__ __launch_bounds__(64) void rescore_buffer_exact_kernel(const float *_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int ld_row = lane >> 4, ld_ch = lane & 15;
-    const float *q = Q + (int64_t)b * D;
-    double acc = 0.0;
-    float4 stage[16];
-    auto load_stage = [&](int c0) {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int64_t row = rows[it * 4 + ld_row];
-            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row >= 0) stage[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
-        }
-    };
-    load_stage(0);
-    for (int c0 = 0; c0 < D; c0 += 64) {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 4 + ld_row;
-            *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
-        }
-        if (c0 + 64 < D) load_stage(c0 + 64);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 e = *reinterpret_cast<const float4 *>(tile + lane * 64 + ((j ^ (lane & 15)) << 2));
-            const float *qp = q + c0 + j * 4;
-            float p0 = qp[0] * e.x;
-            acc += (double)p0;
-            float p1 = qp[1] * e.y;
-            acc += (double)p1;
-            float p2 = qp[2] * e.z;
-            acc += (double)p2;
-            float p3 = qp[3] * e.w;
-            acc += (double)p3;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    const double acc = exact_dot_of_gathered_rows(E, D, Q + (int64_t)b * D, rows, tile, lane);
     if (live) {
         const QueryConst qc = qcs[b];
         const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
         QueryConst exact = qc;
         exact.use_cos = 1;                                   // this path only runs with cosine; guards are inside fused_score
         mine[lane].key = score_key(fused_score(acc, norm_b[my_row], created[my_row], m, exact, now_ticks));
+        buf_dot[(int64_t)b * cap + first + lane] = acc;      // the records take it from here (records_dot_from_buffer)
     }
+}
+
+// Two-stage pass: the records' dots were already computed exactly for the whole buffer; one workgroup per
+// query looks every record's row up in the query's buffer and copies the dot (replaces K6 for this pass).
+__global__ __launch_bounds__(256) void records_dot_from_buffer_kernel(const SelEntry *__restrict__ buf, const double *__restrict__ buf_dot,
+                                                                     const uint32_t *__restrict__ cnt, uint32_t cap, int32_t kprime,
+                                                                     int64_t row_base, orr_candidate *__restrict__ recs)
+{
+    __shared__ uint32_t want[64];
+    const int b = blockIdx.x;
+    orr_candidate *mine = recs + (int64_t)b * (kprime + 1);
+    if (threadIdx.x < 64) {
+        uint32_t w = 0xFFFFFFFFu;
+        if ((int)threadIdx.x < kprime && mine[threadIdx.x].row_id >= 0 && !(mine[threadIdx.x].flags & ORR_CAND_TRAILER))
+            w = (uint32_t)(mine[threadIdx.x].order_key - row_base);
+        want[threadIdx.x] = w;
+    }
+    __syncthreads();
+    const uint32_t n = cnt[b] < cap ? cnt[b] : cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t pos = buf[(int64_t)b * cap + i].pos;
+        for (int c = 0; c < kprime; ++c)
+            if (want[c] == pos) {                              // a row occurs once in a buffer
+                mine[c].dot = buf_dot[(int64_t)b * cap + i];
+                mine[c].flags |= ORR_CAND_DOT_EXACT;
+            }
+    }
+}
+
+hipError_t launch_records_dot_from_buffer(const SelEntry *buf, const double *buf_dot, const uint32_t *cnt, uint32_t cap, int32_t B,
+                                          int32_t kprime, int64_t row_base, orr_candidate *recs, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    if (kprime < 1 || kprime > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(records_dot_from_buffer_kernel, dim3((unsigned)B), dim3(256), 0, s, buf, buf_dot, cnt, cap, kprime, row_base, recs);
+    return hipGetLastError();
 }
 
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
                                        const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
-                                       const uint32_t *cnt, uint32_t cap, SelEntry *buf, hipStream_t s)
+                                       const uint32_t *cnt, uint32_t cap, SelEntry *buf, double *buf_dot, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
     if (D % 64 != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rescore_buffer_exact_kernel, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
-                       now_ticks, cnt, cap, buf);
+                       now_ticks, cnt, cap, buf, buf_dot);
     return hipGetLastError();
 }
 
@@ -951,17 +1000,14 @@ hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n
 // the records' candidate positions.  Writes the reference-order fp64 dot into the record
 // and marks it ORR_CAND_DOT_EXACT.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rescore_exact_kernel(const float *__restrict__ E, int32_t D,
-                                                            const float *__restrict__ Q, int32_t B, int32_t kprime,
-                                                            int64_t row_base, orr_candidate *__restrict__ recs)
+__global__ __launch_bounds__(64) void rescore_exact_kernel(const float *__restrict__ E, int32_t D,
+                                                           const float *__restrict__ Q, int32_t B, int32_t kprime,
+                                                           int64_t row_base, orr_candidate *__restrict__ recs)
 {
-    __shared__ __attribute__((aligned(16))) float tile_all[4][64 * 64];
-    __shared__ int64_t rows_all[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    float *tile = tile_all[wave];
-    int64_t *rows = rows_all[wave];
+    __shared__ __attribute__((aligned(16))) float tile[64 * 64];
+    __shared__ int64_t rows[64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
     orr_candidate *mine = recs + (int64_t)b * (kprime + 1);
     int64_t my_row = -1;
     if (lane < kprime && mine[lane].row_id >= 0 && !(mine[lane].flags & ORR_CAND_TRAILER))
@@ -970,43 +1016,7 @@ __global__ __launch_bounds__(256) void rescore_exact_kernel(const float *__restr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int ld_row = lane >> 4, ld_ch = lane & 15;
-    const float *q = Q + (int64_t)b * D;
-    double acc = 0.0;
-    for (int c0 = 0; c0 < D; c0 += 64) {
-        float4 stage[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 4 + ld_row;
-            const int64_t row = rows[r];
-            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row >= 0) stage[it] = *reinterpret_cast<const float4 *>(E + row * (int64_t)D + c0 + ld_ch * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 4 + ld_row;
-            *reinterpret_cast<float4 *>(tile + r * 64 + ((ld_ch ^ (r & 15)) << 2)) = stage[it];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 e = *reinterpret_cast<const float4 *>(tile + lane * 64 + ((j ^ (lane & 15)) << 2));
-            const float *qp = q + c0 + j * 4;
-            float p0 = qp[0] * e.x;
-            acc += (double)p0;
-            float p1 = qp[1] * e.y;
-            acc += (double)p1;
-            float p2 = qp[2] * e.z;
-            acc += (double)p2;
-            float p3 = qp[3] * e.w;
-            acc += (double)p3;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    const double acc = exact_dot_of_gathered_rows(E, D, Q + (int64_t)b * D, rows, tile, lane);
     if (my_row >= 0) {
         mine[lane].dot = acc;
         mine[lane].flags |= ORR_CAND_DOT_EXACT;
@@ -1039,7 +1049,7 @@ hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32
 {
     if (B <= 0 || D <= 0) return hipSuccess;
     if (kprime <= 64 && D % 64 == 0 && (reinterpret_cast<uintptr_t>(E) & 15) == 0) {
-        hipLaunchKernelGGL(rescore_exact_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, E, D, Q, B, kprime, row_base, recs);
+        hipLaunchKernelGGL(rescore_exact_kernel, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
     } else {
         const int64_t threads = (int64_t)B * kprime;
         hipLaunchKernelGGL(rescore_exact_generic, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, D, Q, B, kprime,

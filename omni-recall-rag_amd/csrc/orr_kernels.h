@@ -152,7 +152,9 @@ hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, do
                                   unsigned long long *floor_key, double *L_out, hipStream_t s);
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
                                        const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
-                                       const uint32_t *cnt, uint32_t cap, SelEntry *buf, hipStream_t s);
+                                       const uint32_t *cnt, uint32_t cap, SelEntry *buf, double *buf_dot, hipStream_t s);
+hipError_t launch_records_dot_from_buffer(const SelEntry *buf, const double *buf_dot, const uint32_t *cnt, uint32_t cap, int32_t B,
+                                          int32_t kprime, int64_t row_base, orr_candidate *recs, hipStream_t s);
 hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint32_t cap, int32_t B, int32_t seg_first,
                                   int32_t n_seg_total, SelEntry *out_sel, hipStream_t s);
 // K2s: the same for B <= 32 queries, streaming (HBM-bound) structure.
