@@ -1044,6 +1044,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     int32_t fused_sample_seg = 0;      // > 0: fused epilogue behind a sampled prefix of that many segments
     bool two_stage = false;            // plain-bf16 first stage over all rows + exact second stage
     bool records_have_dots = false;    // two-stage: exact dots copied from the survivors' buffer
+    bool ts_gemv = false;              // two-stage with the streaming screen for 5..8 queries
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
         if (B <= 64 || getenv("ORR_GEMM_KIND")) {
@@ -1061,6 +1062,22 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);
                 HIP_TRY(orr::launch_gemv_mfma(d_q + (size_t)b0 * a.dim, nq, idx->d_emb, n, idx->dim, d_dotf + (size_t)b0 * n, n, s));
             }
+        } else if (B <= orr::kMaxGemvScreenQ && idx->opt_two_stage == 1 && (ensure_shadow(idx), idx->shadow_ready)) {
+            // 5..8 queries: still HBM-bound, so no GEMM tile: the f32 streaming MFMA kernel over the prefix gives
+            // the floor and the shadow is streamed by the dot2 kernel (K2g) for all queries at once
+            ts_gemv = true;
+            two_stage = true;
+            const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
+            fused_sample_seg = std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16));
+            dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
+            ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
+            d_dotf = idx->ws_dotf.as<float>();
+            {
+                Timed t(idx, "gemv_mfma_prefix", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
+                HIP_TRY(orr::launch_gemv_mfma(d_q, B, idx->d_emb, dotf_rows, idx->dim, d_dotf, dotf_rows, s));
+            }
+            ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
+            HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
         } else {
             static const bool f32_gemm = [] { const char *e = getenv("ORR_GEMM_KIND"); return e && strcmp(e, "f32") == 0; }();
             if (f32_gemm) {
@@ -1273,7 +1290,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             orr::FusedEpilogue epi;
             epi.count_planes = nullptr;
             epi.plane_stride = (n + 63) / 64 * 64;
-            if (kw.bitmaps && !ts_small) {
+            if (kw.bitmaps && !ts_small && !ts_gemv) {
                 Timed t(idx, "count_planes", 4.0 * orr::kCountPlanes * (double)((B + 31) / 32) * (double)n);
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
                 HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s));
@@ -1302,7 +1319,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                        idx->ws_fqf.as<float4>(), s));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (idx->opt_two_stage == 1) ORR_TRY(ensure_shadow(idx));
-                if (ts_small) {
+                if (ts_small || ts_gemv) {
                     Timed t(idx, "screen_gemv_bf16", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, n, idx->dim, epi, s));
                 } else if (idx->opt_two_stage == 1 && idx->shadow_ready) {

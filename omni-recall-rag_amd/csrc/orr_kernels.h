@@ -13,6 +13,7 @@ constexpr int kSelWidth = 64;        // entries a wave keeps while selecting (on
 constexpr int kSelSegRows = 4096;    // rows one workgroup of fuse_select scans
 constexpr int kMaxExactQ = 8;        // queries one launch of the exact dot kernel carries
 constexpr int kMaxScanTerms = 64;    // query terms one launch of the keyword scan carries
+constexpr int kMaxGemvScreenQ = 8;   // queries one launch of the streaming screen (K2g) carries
 constexpr int kCountPlanes = 4;      // bit planes of the per-(query,row) keyword match count (saturates at 15)
 
 // One selection entry: `key` orders scores (see score_key in the .hip), `pos` is the
@@ -144,7 +145,7 @@ size_t bf16_tiled_bytes(int64_t n_rows, int32_t D);
 hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *out, hipStream_t s);
 hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shadow, int64_t row_first, int64_t n_rows,
                               int32_t D, float *S, int64_t s_stride, const FusedEpilogue *epi, hipStream_t s);
-// K2g: the screening pass for 1..4 queries as a stream over the tiled shadow (no matrix core).
+// K2g: the screening pass for 1..kMaxGemvScreenQ queries as a stream over the tiled shadow (no matrix core).
 hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_shadow, int64_t n_rows, int32_t D,
                                    const FusedEpilogue &epi, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     }
 }
 
-// K2g: the same screening pass for 1..4 queries -- no matrix core, a pure stream over the tiled shadow.
+// K2g: the same screening pass for 1..8 queries -- no matrix core, a pure stream over the tiled shadow.
 // Work unit = half a row tile (128 rows x D): per K-tile its 8 KiB are eight 1 KiB wave loads, lane l
 // always holding chunk c = (l & 3) ^ ((l >> 4) & 3) of rows 16 j + (l >> 2), j = 0..7 (the swizzle of the
 // stored layout does not depend on j), so one 16-byte read of the query's hi half from LDS serves all
@@ -312,24 +312,30 @@ hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *ou
     return hipGetLastError();
 }
 
-// The screening pass for B <= 4 queries: q_hi is the linear [B][D] bf16 image (hi halves of
+// The screening pass for B <= kMaxGemvScreenQ queries: q_hi is the linear [B][D] bf16 image (hi halves of
 // launch_split_queries), the fused epilogue is mandatory.
 hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_shadow, int64_t n_rows, int32_t D,
                                    const FusedEpilogue &epi, hipStream_t s)
 {
     if (B <= 0 || n_rows <= 0) return hipSuccess;
-    if (B > 4 || D <= 0 || D % 64 != 0) return hipErrorInvalidValue;
+    if (B > kMaxGemvScreenQ || D <= 0 || D % 64 != 0) return hipErrorInvalidValue;
     const int64_t n_units = ((n_rows + kScBN - 1) / kScBN) * 2;
     const int64_t blocks = std::min<int64_t>((n_units + 3) / 4, 512);
     const size_t lds = sizeof(uint16_t) * (size_t)B * (size_t)D;
     if (lds > 65536) return hipErrorInvalidValue;
     const __bf16 *qh = static_cast<const __bf16 *>(q_hi), *eh = static_cast<const __bf16 *>(e_shadow);
+#define ORR_GEMV(NQ) hipLaunchKernelGGL(screen_gemv_bf16_kernel<NQ>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi)
     switch (B) {
-    case 1: hipLaunchKernelGGL(screen_gemv_bf16_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
-    case 2: hipLaunchKernelGGL(screen_gemv_bf16_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
-    case 3: hipLaunchKernelGGL(screen_gemv_bf16_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
-    default: hipLaunchKernelGGL(screen_gemv_bf16_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, qh, D, eh, n_units, n_rows, epi); break;
+    case 1: ORR_GEMV(1); break;
+    case 2: ORR_GEMV(2); break;
+    case 3: ORR_GEMV(3); break;
+    case 4: ORR_GEMV(4); break;
+    case 5: ORR_GEMV(5); break;
+    case 6: ORR_GEMV(6); break;
+    case 7: ORR_GEMV(7); break;
+    default: ORR_GEMV(8); break;
     }
+#undef ORR_GEMV
     return hipGetLastError();
 }
 

@@ -429,9 +429,10 @@ def test_two_stage_batched_pass_matches_oracle():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow), (topk, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (topk, b)
-    # 1..4 queries: exact dots over the prefix give the floor, the shadow is streamed without the matrix core
+    # 1..8 queries: exact (1..4) or f32-MFMA (5..8) dots over the prefix give the floor, the shadow is streamed
+    # without the matrix core
     idx.set_option("two_stage", 1)
-    for b0, nb in ((0, 1), (2, 1), (3, 1), (0, 4), (4, 3), (100, 2)):
+    for b0, nb in ((0, 1), (2, 1), (3, 1), (0, 4), (4, 3), (100, 2), (0, 8), (1, 6)):
         idx.set_profiling(True)
         rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
         assert "screen_gemv_bf16" in idx.kernel_stats()
