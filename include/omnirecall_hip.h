@@ -191,14 +191,15 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
- *   "two_stage"      0/1/2 (default 1): batches of >= 5 queries over >= 196,608 rows take ONE plain-bf16
- *                    product over all rows
- *                    (bound 2^-7 |q||e| on the dot), keep every (query,row) pair that could reach a lower
+ *   "two_stage"      0/1/2 (default 1): searches over >= 196,608 rows take ONE plain-bf16 product over all
+ *                    rows (bound 2^-7 |q||e| on the dot; a stream for 1..8 queries, an MFMA GEMM for more),
+ *                    keep every (query,row) pair that could reach a lower
  *                    bound of the query's k-th best score, and re-score those in the reference arithmetic on
  *                    the device.  1: the product reads a bf16 shadow copy of the embeddings
  *                    (built at the first such batch, or now if the index is sealed and the option is set
- *                    explicitly; +50 % HBM; silently falls back to 2 when it does not fit).  2: no shadow,
- *                    the fp32 rows are converted inside the kernel.  0: split-bf16 pass over all rows. */
+ *                    explicitly; +50 % HBM; silently falls back to 2 when it does not fit).  2: no shadow:
+ *                    9+ queries convert the fp32 rows inside the kernel, fewer run the exact kernel.
+ *                    0: exact kernel (1..4 queries) / streaming or split-bf16 MFMA pass over all rows. */
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
 
 /* Diagnostic: out[B][orr_index_rows] = the screening dots of the two-stage pass (fp32, host or device

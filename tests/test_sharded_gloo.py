@@ -61,3 +61,25 @@ def test_term_slot_roundtrip():
         assert sh._unpack_terms_fixed(sh._pack_terms_fixed(terms)) == terms
     with pytest.raises(ValueError):
         sh._pack_terms_fixed([b"y" * 200, b"z" * 100])
+
+
+def test_term_slots_round_trip_for_a_whole_batch():
+    """The exchange slots are built from and parsed back into the ABI's packed arrays with numpy."""
+    import importlib
+    import numpy as np
+    from helpers import pkg
+    P = pkg()
+    sh = importlib.import_module("omni_recall_rag_amd.sharded")
+    batch = [[b"alpha", b"beta"], [], [b"x" * 254], [b"\xc3\xa9t\xc3\xa9", b"k8s", b"a"], [b"q"] * 100]
+    packed = P.pack_terms(batch)
+    slots = sh._slots_from_packed(*packed)
+    assert slots.shape == (len(batch), sh.TERM_SLOT) and slots.dtype == np.uint8
+    back = sh._packed_from_slots(slots)
+    assert len(back) == len(batch)
+    assert all(np.array_equal(a, b) for a, b in zip(packed, back.arrays))
+    assert [back[b] for b in range(len(batch))] == batch and list(back) == batch
+    assert all(np.array_equal(a, b) for a, b in zip(P.pack_terms(back), packed))      # PackedTerms passes through
+    with pytest.raises(ValueError):
+        sh._slots_from_packed(*P.pack_terms([[b"y" * 256]]))
+    with pytest.raises(ValueError):
+        sh._slots_from_packed(*P.pack_terms([[b"y" * 200, b"z" * 100]]))
