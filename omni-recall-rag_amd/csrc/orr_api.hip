@@ -945,6 +945,17 @@ bool is_device_pointer(const void *p)
     return attr.type == hipMemoryTypeDevice;
 }
 
+// Rows of the sampled prefix of the two-stage pass, in selection segments (4096 rows each).  A larger
+// sample gives a tighter floor (fewer survivors to re-score) and costs a larger ranking pass.  Measured at
+// 12.5M rows x 1024 queries: 16 / 32 / 64 segments = 88.4 / 90.9 / 95.4 ms per batch, the survivors' re-score
+// staying below 0.3 ms, so 65,536 rows it is until the corpus is large enough to fill the survivor buffers.
+static int32_t sample_segments(int32_t n_seg_all)
+{
+    static const int forced = [] { const char *e = getenv("ORR_TS_SAMPLE_SEGS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return std::min<int32_t>(forced, n_seg_all);
+    return std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 256));
+}
+
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
@@ -1068,7 +1079,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ts_gemv = true;
             two_stage = true;
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-            fused_sample_seg = std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16));
+            fused_sample_seg = sample_segments(n_seg_all);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
             d_dotf = idx->ws_dotf.as<float>();
@@ -1092,7 +1103,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
                 two_stage = idx->opt_two_stage != 0 && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
                 fused_sample_seg = ((idx->opt_fuse_epilogue || two_stage) && !a.no_fuse && n_seg_all >= 48)
-                                       ? std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16)) : 0;
+                                       ? sample_segments(n_seg_all) : 0;
                 dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
                 ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
                 d_dotf = idx->ws_dotf.as<float>();
@@ -1116,7 +1127,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     } else if (ts_small) {
         const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
         two_stage = true;
-        fused_sample_seg = std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 16));
+        fused_sample_seg = sample_segments(n_seg_all);
         dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)dotf_rows));
         d_dot = idx->ws_dot.as<double>();
