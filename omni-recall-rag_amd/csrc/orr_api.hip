@@ -1216,12 +1216,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
         if (V > 0) {
             const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
-            for (uint32_t t0 = 0; t0 < TT; t0 += orr::kMaxScanTerms) {      // every distinct term is its own 1-term "query"
-                const int32_t nt = (int32_t)std::min<uint32_t>(orr::kMaxScanTerms, TT - t0);
+            {   // every distinct term is its own 1-term "query"; all groups of 64 terms in one launch
                 Timed t(idx, "vocab_scan", 0.0, k);
-                HIP_TRY(orr::launch_keyword_scan(idx->d_vpool, idx->d_vstart, idx->d_vlen, V, dm + off_pool, d_terms + t0, nt,
-                                                 reinterpret_cast<const uint32_t *>(dm + off_iota), nt,
-                                                 idx->ws_vmatch.as<uint16_t>() + (size_t)t0 * V, V, 0, k));
+                HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->d_vstart, idx->d_vlen, V, dm + off_pool, d_terms, (int32_t)TT,
+                                               reinterpret_cast<const uint32_t *>(dm + off_iota), idx->ws_vmatch.as<uint16_t>(), k));
             }
             {
                 Timed t(idx, "vocab_hits", 0.0, k);

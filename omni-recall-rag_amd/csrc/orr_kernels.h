@@ -53,6 +53,11 @@ hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *cstart, cons
                                const uint32_t *q_term_off, int32_t B, uint16_t *matches,
                                int64_t matches_stride, int32_t accumulate, hipStream_t s);
 
+// The same scan over the shard's VOCABULARY for every distinct query term at once (one launch).
+hipError_t launch_vocab_scan(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
+                             const uint8_t *term_pool, const ScanTerm *terms, int32_t n_terms, const uint32_t *identity,
+                             uint16_t *vmatch, hipStream_t s);
+
 // Keyword side of a batch as the scoring kernels see it: one row bitmap per DISTINCT
 // query term (bit r of bitmaps[t*words_per_term + r/32] = term t occurs in row r) and
 // each query's list of distinct-term indices.  bitmaps == nullptr: no query has terms.

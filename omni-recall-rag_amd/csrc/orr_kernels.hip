@@ -249,8 +249,17 @@ __global__ __launch_bounds__(256) void keyword_scan_kernel(const uint8_t *__rest
                                                            const ScanTerm *__restrict__ terms, int32_t n_terms,
                                                            const uint32_t *__restrict__ q_term_off, int32_t B,
                                                            uint16_t *__restrict__ matches, int64_t matches_stride,
-                                                           int32_t accumulate)
+                                                           int32_t accumulate, int32_t group_terms)
 {
+    // group_terms > 0 (vocabulary form): blockIdx.y selects a group of single-term "queries"; n_terms is the
+    // total, q_term_off the identity table 0..group_terms
+    if (group_terms > 0) {
+        const int32_t first = (int32_t)blockIdx.y * group_terms;
+        terms += first;
+        matches += (int64_t)first * matches_stride;
+        n_terms = n_terms - first < group_terms ? n_terms - first : group_terms;
+        B = n_terms;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + uniform32((int)(threadIdx.x >> 6));
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -322,7 +331,25 @@ hipError_t launch_keyword_scan(const uint8_t *pool, const uint64_t *cstart, cons
     int64_t blocks = (n_rows + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(keyword_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pool, cstart, clen, n_rows, term_pool,
-                       terms, n_terms, q_term_off, B, matches, matches_stride, accumulate);
+                       terms, n_terms, q_term_off, B, matches, matches_stride, accumulate, 0);
+    return hipGetLastError();
+}
+
+// Vocabulary form: every one of n_terms distinct terms is its own single-term query; vmatch[t][v] = 1 iff
+// term t occurs inside token v.  All groups of kMaxScanTerms terms run in ONE launch (grid.y), which matters
+// when the vocabulary is small and a launch is mostly latency.  identity = {0, 1, ..., kMaxScanTerms}.
+hipError_t launch_vocab_scan(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
+                             const uint8_t *term_pool, const ScanTerm *terms, int32_t n_terms, const uint32_t *identity,
+                             uint16_t *vmatch, hipStream_t s)
+{
+    if (n_tokens <= 0 || n_terms <= 0) return hipSuccess;
+    const int32_t groups = (n_terms + kMaxScanTerms - 1) / kMaxScanTerms;
+    if (groups > 65535) return hipErrorInvalidValue;
+    int64_t blocks = (n_tokens + 3) / 4;
+    const int64_t cap = std::max<int64_t>(64, (256 * 8) / groups);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(keyword_scan_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, s, vpool, vstart, vlen, n_tokens,
+                       term_pool, terms, n_terms, identity, 0, vmatch, n_tokens, 0, kMaxScanTerms);
     return hipGetLastError();
 }
 
