@@ -48,6 +48,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="single-GPU runs: steps are issued from this many threads, each on its own search lane "
+                         "(orr_index_view), so the host finish and the small kernels of one step overlap the "
+                         "dominant kernel of another")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra two-steps-in-flight measurement")
     ap.add_argument("--no-terms", action="store_true", help="diagnostic: queries without keyword terms")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="orr_index_set_option on the shard before the run (e.g. two_stage=1)")
@@ -138,27 +143,87 @@ def main():
         term_steps.append([[] if args.no_terms else P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])
     torch.cuda.synchronize()
 
-    def step(s):
+    n_lanes = max(1, args.inflight) if front is None else 1
+    lanes = [idx] + [idx.view() for _ in range(n_lanes - 1)]
+
+    def step(s, lane=0):
         if front is not None:
             return front.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, n_total)
-        return idx.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
+        return lanes[lane].search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
 
     for s in range(args.warmup):
-        step(s)
-    idx.set_profiling(True)
+        step(s, s % n_lanes)
+    for ln in lanes:
+        ln.set_profiling(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    results = {}
     t0 = time.perf_counter()
-    last = None
-    for s in range(args.warmup, n_steps_total):
-        last = step(s)
+    if n_lanes == 1:
+        for s in range(args.warmup, n_steps_total):
+            results[s] = step(s)
+    else:
+        import threading
+
+        def run_lane(lane):
+            for s in range(args.warmup + lane, n_steps_total, n_lanes):
+                results[s] = step(s, lane)
+
+        threads = [threading.Thread(target=run_lane, args=(ln,)) for ln in range(n_lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    stats = idx.kernel_stats()
-    idx.set_profiling(False)
+    last = results[n_steps_total - 1]
+
+    stats = {}
+    for ln in lanes:
+        for name, v in ln.kernel_stats().items():
+            acc = stats.setdefault(name, {"launches": 0, "total_ms": 0.0, "algo_bytes": 0.0})
+            for key in acc:
+                acc[key] += v[key]
+        ln.set_profiling(False)
+
+    # Reported beside the headline, not as it: the same steps again with two of them in flight (two threads,
+    # the second on a view of the shard), which is how concurrent requests reach the service.
+    overlap = None
+    if front is None and n_lanes == 1 and not args.no_overlap_leg:
+        import threading
+        lane2 = None
+        try:
+            lane2 = idx.view()
+            both = [idx, lane2]
+            errors = []
+
+            def run2(lane):
+                try:
+                    for s in range(args.warmup + lane, n_steps_total, 2):
+                        both[lane].search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
+                except Exception as exc:         # e.g. no room for a second set of workspaces
+                    errors.append(repr(exc))
+
+            for _ in range(2):                   # the first round warms the view's workspaces
+                threads = [threading.Thread(target=run2, args=(ln,)) for ln in range(2)]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+            overlap = {"steps_in_flight": 2, "value": args.steps * B_local / dt2, "unit": "queries/s",
+                       "ms_per_step": 1e3 * dt2 / args.steps} if not errors else {"steps_in_flight": 2, "error": errors[0]}
+        except Exception as exc:
+            overlap = {"steps_in_flight": 2, "error": repr(exc)}
+        finally:
+            if lane2 is not None:
+                lane2.close()
 
     # sanity inside the bench: the planted row of the last step must be rank 1
     planted = syn.planted_rows(((n_steps_total - 1) * world + rank) * B_local, B_local, n_total)
@@ -225,8 +290,10 @@ def main():
             "config": {"workload": f"C2: {rows} chunks x {dim}-d fp32 per GPU, {B_local} query per GPU per step, "
                                    f"top-k={k}, full hybrid (cosine+keyword+recency), candidate_limit=corpus",
                        "corpus_rows": n_total, "queries_per_step": world * B_local, "options": args.set_option,
+                       "steps_in_flight": n_lanes,
                        "parallelism": f"row-sharded x{world}, all-gather of per-shard top-k'" if world > 1 else "single GPU"},
             "row_scores_per_sec": queries * n_total / elapsed,
+            "two_steps_in_flight": overlap,
             "rank1_is_planted_row": ok,
             "roofline": roofline,
             "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
@@ -238,6 +305,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    for ln in lanes[1:]:
+        ln.close()
     idx.close()
 
 

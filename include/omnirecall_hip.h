@@ -187,6 +187,15 @@ int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_
 int orr_index_save(orr_index *idx, const char *path);
 int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
 
+/* ---- a second search lane ---------------------------------------------------
+ * orr_index_view: another handle over the same SEALED shard with its own streams and workspaces.  It
+ * borrows the corpus (and the bf16 shadow, built first if the two-stage pass is on): nothing is copied.
+ * Searches on the index and on its views may run concurrently from different threads, which lets the
+ * keyword chain, the ranking pass and the host finish of one batch overlap the screening pass of another
+ * (the request path of Program.cs:59 is concurrent by nature).  A view must be destroyed before its
+ * parent; it cannot be appended to, sealed again or saved. */
+int orr_index_view(orr_index *parent, orr_index **view);
+
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter

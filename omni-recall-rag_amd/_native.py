@@ -82,6 +82,8 @@ hip.orr_index_load.restype = C.c_int
 hip.orr_index_load.argtypes = [C.POINTER(OrrConfig), C.c_char_p, C.POINTER(_vp)]
 hip.orr_index_set_option.restype = C.c_int
 hip.orr_index_set_option.argtypes = [_vp, C.c_char_p, _i64]
+hip.orr_index_view.restype = C.c_int
+hip.orr_index_view.argtypes = [_vp, C.POINTER(_vp)]
 hip.orr_index_screen_dots.restype = C.c_int
 hip.orr_index_screen_dots.argtypes = [_vp, _i32, _i32, _vp, _vp]
 hip.orr_index_set_profiling.restype = C.c_int
@@ -143,7 +145,7 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
     "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
-    "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots",
+    "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_view",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",

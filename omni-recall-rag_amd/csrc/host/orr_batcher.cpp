@@ -1,6 +1,9 @@
 // orr_batcher.cpp -- request micro-batcher in front of orr_search_batch
-// (include/omnirecall_host.h).  One worker thread per batcher; callers block on a
-// condition variable until their slice of the batch result is ready.
+// (include/omnirecall_host.h).  Callers block on a condition variable until their slice of the
+// batch result is ready.  Two worker threads when the index is sealed: the second one searches
+// through a view of the index (orr_index_view: own streams and workspaces, shared corpus), so
+// while one batch is in its screening pass the next one is already collected and running its
+// keyword chain and ranking pass.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -42,7 +45,8 @@ struct orrh_batcher {
     std::condition_variable cv_work, cv_done;
     std::deque<Request *> queue;
     bool stop = false;
-    std::thread worker;
+    std::thread worker, worker2;
+    orr_index *view = nullptr;     // second lane (null when the index was not sealed at creation)
     int64_t batches = 0, requests = 0;
     int32_t largest = 0;
 };
@@ -54,7 +58,7 @@ bool compatible(const Request *a, const Request *b)
     return a->dim == b->dim && a->now_ticks == b->now_ticks && a->candidate_limit == b->candidate_limit;
 }
 
-void run_batch(orrh_batcher *b, std::vector<Request *> &batch)
+void run_batch(orr_index *index, std::vector<Request *> &batch)
 {
     const int32_t B = (int32_t)batch.size();
     const int32_t dim = batch[0]->dim;
@@ -77,7 +81,7 @@ void run_batch(orrh_batcher *b, std::vector<Request *> &batch)
     std::vector<int64_t> rows((size_t)B * topk, -1);
     std::vector<double> scores((size_t)B * topk, 0.0);
     std::vector<int32_t> counts((size_t)B, 0);
-    const int st = orr_search_batch(b->index, B, dim, dim > 0 ? q.data() : nullptr, terms.data(), term_off.data(), qoff.data(),
+    const int st = orr_search_batch(index, B, dim, dim > 0 ? q.data() : nullptr, terms.data(), term_off.data(), qoff.data(),
                                     batch[0]->now_ticks, topk, batch[0]->candidate_limit, rows.data(), scores.data(),
                                     counts.data());
     for (int32_t i = 0; i < B; ++i) {
@@ -95,7 +99,7 @@ void run_batch(orrh_batcher *b, std::vector<Request *> &batch)
     }
 }
 
-void worker_loop(orrh_batcher *b)
+void worker_loop(orrh_batcher *b, orr_index *index)
 {
     std::unique_lock<std::mutex> lk(b->mu);
     for (;;) {
@@ -117,7 +121,7 @@ void worker_loop(orrh_batcher *b)
             if (b->cv_work.wait_until(lk, deadline) == std::cv_status::timeout) break;
         }
         lk.unlock();
-        run_batch(b, batch);
+        run_batch(index, batch);
         lk.lock();
         b->batches += 1;
         b->requests += (int64_t)batch.size();
@@ -138,7 +142,8 @@ orrh_batcher *orrh_batcher_create(void *index, int32_t max_batch, int32_t max_wa
     b->index = static_cast<orr_index *>(index);
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
-    b->worker = std::thread(worker_loop, b);
+    b->worker = std::thread(worker_loop, b, b->index);
+    if (orr_index_view(b->index, &b->view) == ORR_OK) b->worker2 = std::thread(worker_loop, b, b->view);
     return b;
 }
 
@@ -151,6 +156,8 @@ void orrh_batcher_destroy(orrh_batcher *b)
     }
     b->cv_work.notify_all();
     if (b->worker.joinable()) b->worker.join();
+    if (b->worker2.joinable()) b->worker2.join();
+    if (b->view) orr_index_destroy(b->view);
     delete b;
 }
 

@@ -156,6 +156,7 @@ struct orr_index {
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     std::vector<double> h_norm_a;      // exact query norms of the batch in flight (run_shard -> host finish)
     bool sealed = false;
+    bool is_view = false;              // a second search lane over another index's sealed corpus (orr_index_view)
     bool opt_fuse_epilogue = false;
     int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
     DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
@@ -433,18 +434,22 @@ void orr_index_destroy(orr_index *idx)
     if (idx->stream_kw) (void)hipStreamDestroy(idx->stream_kw);
     for (auto &pe : idx->pending) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
     for (auto e : idx->event_pool) (void)hipEventDestroy(e);
-    if (idx->d_emb) (void)hipFree(idx->d_emb);
-    if (idx->d_created) (void)hipFree(idx->d_created);
-    if (idx->d_row_ids) (void)hipFree(idx->d_row_ids);
-    if (idx->d_cstart) (void)hipFree(idx->d_cstart);
-    if (idx->d_clen) (void)hipFree(idx->d_clen);
-    if (idx->d_pool) (void)hipFree(idx->d_pool);
-    if (idx->d_norm_b) (void)hipFree(idx->d_norm_b);
-    if (idx->d_vpool) (void)hipFree(idx->d_vpool);
-    if (idx->d_vstart) (void)hipFree(idx->d_vstart);
-    if (idx->d_vlen) (void)hipFree(idx->d_vlen);
-    if (idx->d_post_off) (void)hipFree(idx->d_post_off);
-    if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
+    if (!idx->is_view) {                               // a view borrows the corpus and the shadow
+        if (idx->d_emb) (void)hipFree(idx->d_emb);
+        if (idx->d_created) (void)hipFree(idx->d_created);
+        if (idx->d_row_ids) (void)hipFree(idx->d_row_ids);
+        if (idx->d_cstart) (void)hipFree(idx->d_cstart);
+        if (idx->d_clen) (void)hipFree(idx->d_clen);
+        if (idx->d_pool) (void)hipFree(idx->d_pool);
+        if (idx->d_norm_b) (void)hipFree(idx->d_norm_b);
+        if (idx->d_vpool) (void)hipFree(idx->d_vpool);
+        if (idx->d_vstart) (void)hipFree(idx->d_vstart);
+        if (idx->d_vlen) (void)hipFree(idx->d_vlen);
+        if (idx->d_post_off) (void)hipFree(idx->d_post_off);
+        if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
+    } else {
+        idx->emb_shadow.p = nullptr; idx->emb_shadow.cap = 0;
+    }
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
@@ -697,6 +702,7 @@ int orr_index_save(orr_index *idx, const char *path)
     if (!idx || !path) return fail(ORR_EINVAL, "orr_index_save: null argument");
     std::lock_guard<std::mutex> lock(idx->mu);
     if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_save: index is not sealed");
+    if (idx->is_view) return fail(ORR_ESTATE, "orr_index_save: save the owning index, not a view");
     ORR_TRY(bind_device(idx));
     FILE *f = fopen(path, "wb");
     if (!f) return fail(ORR_EINVAL, "orr_index_save: cannot open %s", path);
@@ -810,6 +816,7 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
 // allocation does not fit, the two-stage pass converts in the kernel instead (orr_gemm.hip, PROD = 1).
 static int ensure_shadow(orr_index *idx)
 {
+    if (idx->is_view) return ORR_OK;                   // taken from the parent at creation, or absent
     if (idx->shadow_ready || idx->shadow_failed || !idx->sealed || idx->n_rows <= 0 || idx->dim <= 0 || idx->dim % 64 != 0) return ORR_OK;
     const size_t bytes = orr::bf16_tiled_bytes(idx->n_rows, idx->dim);
     size_t free_b = 0, total_b = 0;
@@ -843,6 +850,39 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
         return ORR_OK;
     }
     return fail(ORR_EINVAL, "orr_index_set_option: unknown option %s", name);
+}
+
+int orr_index_view(orr_index *parent, orr_index **out)
+{
+    if (!parent || !out) return fail(ORR_EINVAL, "orr_index_view: null argument");
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(parent->mu);
+    if (!parent->sealed) return fail(ORR_ESTATE, "orr_index_view: the index is not sealed");
+    if (parent->is_view) return fail(ORR_EINVAL, "orr_index_view: take views of the owning index");
+    HIP_TRY(hipSetDevice(parent->device));
+    if (parent->opt_two_stage == 1) ORR_TRY(ensure_shadow(parent));
+    orr_index *v = new (std::nothrow) orr_index();
+    if (!v) return fail(ORR_ENOMEM, "out of host memory");
+    v->is_view = true;
+    v->device = parent->device; v->dim = parent->dim; v->row_base = parent->row_base;
+    v->n_rows = parent->n_rows; v->cap_rows = parent->cap_rows;
+    v->d_emb = parent->d_emb; v->d_created = parent->d_created; v->d_row_ids = parent->d_row_ids; v->d_norm_b = parent->d_norm_b;
+    v->n_tokens = parent->n_tokens; v->d_vpool = parent->d_vpool; v->d_vstart = parent->d_vstart; v->d_vlen = parent->d_vlen;
+    v->d_post_off = parent->d_post_off; v->d_post_rows = parent->d_post_rows; v->n_postings = parent->n_postings;
+    v->sealed = true;
+    v->opt_fuse_epilogue = parent->opt_fuse_epilogue; v->opt_two_stage = parent->opt_two_stage;
+    v->emb_shadow.p = parent->emb_shadow.p; v->emb_shadow.cap = 0;           // borrowed, never freed here
+    v->shadow_ready = parent->shadow_ready; v->shadow_failed = !parent->shadow_ready;
+    if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&v->stream_kw, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_inputs, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_q, hipEventDisableTiming) != hipSuccess) {
+        orr_index_destroy(v);
+        return fail(ORR_EDEVICE, "cannot create streams on device %d", parent->device);
+    }
+    *out = v;
+    return ORR_OK;
 }
 
 int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, float *out)

@@ -170,6 +170,17 @@ class RecallIndex:
                                        int(kprime), int(candidate_limit), _ptr(out)))
         return out
 
+    def view(self) -> "RecallIndex":
+        """orr_index_view: a second search lane over this sealed shard (own streams and workspaces, shared
+        corpus).  Searches on the index and on its views may run concurrently from different threads."""
+        h = C.c_void_p()
+        N.check(N.hip.orr_index_view(self._h, C.byref(h)))
+        v = RecallIndex.__new__(RecallIndex)
+        v.__dict__.update(self.__dict__)
+        v._h = h
+        v._parent = self                     # keeps the owner alive; close views before it
+        return v
+
     def set_option(self, name: str, value: int) -> None:
         N.check(N.hip.orr_index_set_option(self._h, name.encode(), int(value)))
 

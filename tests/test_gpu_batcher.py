@@ -6,7 +6,7 @@ import threading
 import numpy as np
 import pytest
 
-from helpers import NOW, build_index, oracle_corpus, pkg, random_corpus
+from helpers import DAY, NOW, build_index, oracle_corpus, pkg, random_corpus
 
 pytestmark = pytest.mark.gpu
 
@@ -66,4 +66,52 @@ def test_concurrent_unbatched_searches_are_serialised_safely():
     for i in range(24):
         orow, osc, _ = corpus.search(qs[i], "alpha beta", NOW, 5, candidate_limit=n)
         assert list(out[i][0][0]) == list(orow) and np.array_equal(out[i][1][0], osc)
+    idx.close()
+
+
+def test_views_search_concurrently_and_agree_with_the_owner():
+    """orr_index_view: two lanes over one sealed shard searched from two threads at once return what the
+    owner returns alone (single queries and batches, two-stage pass included)."""
+    import threading
+    P = pkg()
+    rng = np.random.default_rng(123)
+    n, dim = 200_000, 64
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm"])
+    contents = [" ".join(w).encode() for w in words[rng.integers(0, len(words), (n, 4))]]
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], contents[r0:r0 + 50_000])
+    idx.seal()
+    view = idx.view()
+    with pytest.raises(P.OrrError):
+        view.append(emb[:1], created[:1], contents[:1])
+    qs = rng.standard_normal((64, dim)).astype(np.float32)
+    terms = [[b"alpha"], [b"helm", b"beta"], []] * 21 + [[b"gamma"]]
+    want_single = [idx.search(qs[b:b + 1], terms[b:b + 1], NOW, 10, candidate_limit=n) for b in range(16)]
+    want_batch = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    got = {}
+
+    def lane(name, index):
+        out = []
+        for rep in range(3):
+            for b in range(16):
+                out.append(index.search(qs[b:b + 1], terms[b:b + 1], NOW, 10, candidate_limit=n))
+            out.append(index.search(qs, terms, NOW, 10, candidate_limit=n))
+        got[name] = out
+
+    threads = [threading.Thread(target=lane, args=("owner", idx)), threading.Thread(target=lane, args=("view", view))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for name in ("owner", "view"):
+        res = got[name]
+        assert len(res) == 3 * 17
+        for rep in range(3):
+            for b in range(16):
+                assert all(np.array_equal(x, y) for x, y in zip(res[rep * 17 + b], want_single[b])), (name, rep, b)
+            assert all(np.array_equal(x, y) for x, y in zip(res[rep * 17 + 16], want_batch)), (name, rep)
+    view.close()
     idx.close()
