@@ -996,6 +996,18 @@ static int32_t sample_segments(int32_t n_seg_all)
     return std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 256));
 }
 
+// The streaming form (1..8 queries) re-scores its survivors in parallel waves whose time does not grow with
+// their number, so its sample only has to keep the survivors (about 2 k n / sample per query) well inside
+// the 8192-entry buffers: k n / 2000 rows, at least two segments.
+static int32_t sample_segments_small_batch(int32_t n_seg_all, int64_t n, int32_t k)
+{
+    static const int forced = [] { const char *e = getenv("ORR_TS_SAMPLE_SEGS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return std::min<int32_t>(forced, n_seg_all);
+    const int64_t rows = (int64_t)std::max<int32_t>(1, k) * n / 2000;
+    const int64_t segs = (rows + orr::kSelSegRows - 1) / orr::kSelSegRows;
+    return (int32_t)std::min<int64_t>(64, std::max<int64_t>(2, segs));
+}
+
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
@@ -1119,7 +1131,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ts_gemv = true;
             two_stage = true;
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-            fused_sample_seg = sample_segments(n_seg_all);
+            fused_sample_seg = sample_segments_small_batch(n_seg_all, n, a.topk);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
             d_dotf = idx->ws_dotf.as<float>();
@@ -1167,7 +1179,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     } else if (ts_small) {
         const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
         two_stage = true;
-        fused_sample_seg = sample_segments(n_seg_all);
+        fused_sample_seg = sample_segments_small_batch(n_seg_all, n, a.topk);
         dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)dotf_rows));
         d_dot = idx->ws_dot.as<double>();
