@@ -986,26 +986,20 @@ bool is_device_pointer(const void *p)
 }
 
 // Rows of the sampled prefix of the two-stage pass, in selection segments (4096 rows each).  A larger
-// sample gives a tighter floor (fewer survivors to re-score) and costs a larger ranking pass.  Measured at
-// 12.5M rows x 1024 queries: 16 / 32 / 64 segments = 88.4 / 90.9 / 95.4 ms per batch, the survivors' re-score
-// staying below 0.3 ms, so 65,536 rows it is until the corpus is large enough to fill the survivor buffers.
-static int32_t sample_segments(int32_t n_seg_all)
-{
-    static const int forced = [] { const char *e = getenv("ORR_TS_SAMPLE_SEGS"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return std::min<int32_t>(forced, n_seg_all);
-    return std::min<int32_t>(64, std::max<int32_t>(16, n_seg_all / 256));
-}
-
-// The streaming form (1..8 queries) re-scores its survivors in parallel waves whose time does not grow with
-// their number, so its sample only has to keep the survivors (about 2 k n / sample per query) well inside
-// the 8192-entry buffers: k n / 2000 rows, at least two segments.
-static int32_t sample_segments_small_batch(int32_t n_seg_all, int64_t n, int32_t k)
+// sample gives a tighter floor (fewer survivors to re-score) and costs a larger ranking pass; the survivors
+// of one query are about 2 k n / sample when scores are continuous (far fewer when keyword matches make
+// them step-like), and they must stay well inside the 8192-entry buffers: k n / 2000 rows.  Measured (full
+// hybrid scores): 1M rows x 1024 queries, 4 / 8 / 16 segments = 9.7 / 10.4 / 11.3 ms per batch; 12.5M rows x
+// 1024 queries, 4 / 16 / 64 segments = 84.3 / 86.8 / 95.4 ms; the re-score stays below 0.4 ms throughout.
+// The streaming form (1..8 queries) re-scores in parallel waves whose time does not grow with the number
+// of survivors, so it goes down to two segments.
+static int32_t sample_segments(int32_t n_seg_all, int64_t n, int32_t k, bool small_batch)
 {
     static const int forced = [] { const char *e = getenv("ORR_TS_SAMPLE_SEGS"); return e ? atoi(e) : 0; }();
     if (forced > 0) return std::min<int32_t>(forced, n_seg_all);
     const int64_t rows = (int64_t)std::max<int32_t>(1, k) * n / 2000;
     const int64_t segs = (rows + orr::kSelSegRows - 1) / orr::kSelSegRows;
-    return (int32_t)std::min<int64_t>(64, std::max<int64_t>(2, segs));
+    return (int32_t)std::min<int64_t>(64, std::max<int64_t>(small_batch ? 2 : 4, segs));
 }
 
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
@@ -1131,7 +1125,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ts_gemv = true;
             two_stage = true;
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-            fused_sample_seg = sample_segments_small_batch(n_seg_all, n, a.topk);
+            fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
             d_dotf = idx->ws_dotf.as<float>();
@@ -1155,7 +1149,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
                 two_stage = idx->opt_two_stage != 0 && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
                 fused_sample_seg = ((idx->opt_fuse_epilogue || two_stage) && !a.no_fuse && n_seg_all >= 48)
-                                       ? sample_segments(n_seg_all) : 0;
+                                       ? sample_segments(n_seg_all, n, a.topk, false) : 0;
                 dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
                 ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
                 d_dotf = idx->ws_dotf.as<float>();
@@ -1179,7 +1173,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     } else if (ts_small) {
         const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
         two_stage = true;
-        fused_sample_seg = sample_segments_small_batch(n_seg_all, n, a.topk);
+        fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true);
         dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)dotf_rows));
         d_dot = idx->ws_dot.as<double>();

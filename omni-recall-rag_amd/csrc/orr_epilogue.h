@@ -20,12 +20,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // LDS (the operand images are dead by now; the caller has put a workgroup barrier in between).
 // Pass 2 (one copy of the code): fp64 score from the term bitmaps, compare with the floor key,
 // atomic append to the query's buffer.  A non-finite accumulator (fp32 overflow) is never
-// filtered.  A thread whose queue overflows bumps the query's counter past the buffer capacity,
-// which the host treats like any other overflow (the batch is repeated unfused).
+// filtered.  A thread whose queue is full (a "hot" tile: e.g. the newest rows pass for every query)
+// appends further elements straight to the buffers when RESCORED says that every buffer entry gets its
+// exact key afterwards anyway (two-stage pass); otherwise it bumps the query's counter past the buffer
+// capacity, which the host treats like any other overflow (the batch is repeated unfused).
 constexpr int kEpiQueue = 8;            // parked elements per thread
 struct EpiParked { float a; uint32_t idx; };
 
-template <int NI, int NJ>
+template <int NI, int NJ, bool RESCORED>
 __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int qbase, int64_t colbase, int32_t B,
                                                int64_t n_rows, const FusedEpilogue &epi, int lane, EpiParked *queue,
                                                int queue_stride)
@@ -73,6 +75,13 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
                         EpiParked pk;
                         pk.a = a; pk.idx = (uint32_t)((i * 16 + e) * NJ + j);
                         queue[parked * queue_stride] = pk;
+                    } else if (RESCORED) {
+                        const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
+                        if (slot < epi.cap) {
+                            SelEntry en;
+                            en.key = ~0ull; en.pos = (uint32_t)cols[j]; en.pad = 0;   // the exact re-score sets the key
+                            epi.buf[(int64_t)qi * epi.cap + slot] = en;
+                        }
                     } else {
                         atomicAdd(&epi.cnt[qi], epi.cap + 1u);             // forces the overflow route for this query
                     }

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
             }
     } else {
         __syncthreads();                                                    // every wave is done with the operand images
-        fused_epilogue<2, NT>(acc, b0 + wm * 64, n0 + wn * 32 * NT, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(img) + tid, 512);
+        fused_epilogue<2, NT, PROD == 1>(acc, b0 + wm * 64, n0 + wn * 32 * NT, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(img) + tid, 512);
     }
 }
 

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
             }
     } else {
         __syncthreads();                                                    // every wave is done with the operand images
-        fused_epilogue<4, 2>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+        fused_epilogue<4, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
     }
 }
 

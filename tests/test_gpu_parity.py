@@ -454,6 +454,43 @@ def test_two_stage_batched_pass_matches_oracle():
     idx.close()
 
 
+def test_two_stage_pass_with_rows_that_are_hot_for_every_query():
+    """The 1,500 newest rows are near-duplicates of one chunk and carry the full recency credit, and no query
+    has terms: for a query they score within the screening margin of each other, so whole tiles of the
+    screening GEMM pass the pre-filter for every query that likes that chunk at all.  The epilogue must cope
+    (per-thread queues overflow into direct appends) without falling back, and the result stays exact."""
+    P = pkg()
+    rng = np.random.default_rng(79)
+    n, dim, B = 200_000, 64, 130
+    emb = (rng.standard_normal((n, dim)) * 0.2).astype(np.float32)
+    emb[:1500] = emb[0] + (rng.standard_normal((1500, dim)) * 1e-4).astype(np.float32)   # near-duplicates of one chunk
+    created = np.empty(n, dtype=np.int64)
+    created[:1500] = NOW - rng.integers(0, DAY // 4, 1500)             # a few hours old
+    created[1500:] = NOW - rng.integers(200 * DAY, 300 * DAY, n - 1500)
+    created = np.sort(created)[::-1].astype(np.int64)
+    contents = [b"x"] * n
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], contents[r0:r0 + 50_000])
+    idx.seal()
+    qs = (emb[0][None, :] * rng.uniform(0.5, 2.0, (B, 1)) + rng.standard_normal((B, dim)) * 0.15).astype(np.float32)   # all like that chunk
+    terms = [[] for _ in range(B)]
+    idx.set_profiling(True)
+    rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    stats = idx.kernel_stats()
+    idx.set_profiling(False)
+    assert stats["screen_bf16_fused"]["launches"] == 1 and stats["gemm_dot_bf16x3"]["launches"] == 1, stats
+    assert (rows < 1500).all()                                             # every result is one of the hot rows
+    corpus = orc.OracleCorpus(emb, created, contents)
+    for b in (0, 1, 64, 129):
+        orow, osc, _ = corpus.search(qs[b], "", NOW, 10, candidate_limit=n, threads=8)
+        assert list(rows[b, :counts[b]]) == list(orow), b
+        assert np.array_equal(scores[b, :counts[b]], osc), b
+    r1, s1, c1 = idx.search(qs[:1], terms[:1], NOW, 10, candidate_limit=n)    # streaming form, same rows
+    assert np.array_equal(r1[0], rows[0]) and np.array_equal(s1[0], scores[0])
+    idx.close()
+
+
 def test_empty_and_degenerate_inputs():
     """Empty corpus, rows with empty content, queries without terms or vectors, API misuse."""
     P = pkg()
