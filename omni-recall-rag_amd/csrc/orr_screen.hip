@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     // iteration ago).
     // One LDS-DMA piece per pair of MFMAs in the first half of the tile.  (Measured alternatives, 1M x 3072
     // rows x 256 queries: all four pieces right after the barrier, or the SIMD's two waves taking the
-    // request half and the multiply half of the period in opposite order: both 5-8 % slower.)
+    // request half and the multiply half of the period in opposite order: both 5-8 % slower;
+    // s_setprio(1) around every MFMA pair: no gain.)
 #define ORR_TILE(CUR0, CUR1, NXT0, NXT1, t) \
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (kScNS - 3)) : "memory"); \
     issue_piece((t) + kScNS - 1, 0); ORR_SB; \

@@ -87,6 +87,10 @@ def test_views_search_concurrently_and_agree_with_the_owner():
     view = idx.view()
     with pytest.raises(P.OrrError):
         view.append(emb[:1], created[:1], contents[:1])
+    with pytest.raises(P.OrrError):
+        view.view()                                    # views are taken of the owner
+    with pytest.raises(P.OrrError):
+        view.save("/tmp/orr_view_must_not_save.bin")
     qs = rng.standard_normal((64, dim)).astype(np.float32)
     terms = [[b"alpha"], [b"helm", b"beta"], []] * 21 + [[b"gamma"]]
     want_single = [idx.search(qs[b:b + 1], terms[b:b + 1], NOW, 10, candidate_limit=n) for b in range(16)]
