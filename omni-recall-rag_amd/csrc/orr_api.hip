@@ -163,7 +163,7 @@ struct orr_index {
     bool shadow_ready = false, shadow_failed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -451,7 +451,7 @@ void orr_index_destroy(orr_index *idx)
         idx->emb_shadow.p = nullptr; idx->emb_shadow.cap = 0;
     }
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
-                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -1033,18 +1033,17 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     // Batched candidate pass on the matrix cores (K2) + exact re-score (K6) from this batch size
     // up; below it the HBM-bound exact kernel is as fast and needs no second pass.
     static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
-    const bool use_mfma = use_cos && !a.force_exact && B >= mfma_min_batch && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
-    // 1..4 queries: the exact kernel reads all 12 KiB of every row; with the bf16 shadow in place the same
-    // two-stage idea applies without the matrix core: exact dots over a sampled prefix give the floor, a
-    // stream over the shadow (half the bytes) keeps what can reach it, the survivors are re-scored exactly.
-    bool ts_small = false;
-    if (use_cos && !use_mfma && !a.force_exact && !a.no_fuse && idx->opt_two_stage == 1 && idx->dim % 64 == 0 &&
-        kprime <= orr::kSelWidth && (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
-        B <= 4) {
+    // 1..8 queries over a large shard with the bf16 shadow in place: the streaming form of the two-stage pass
+    // (f32 streaming MFMA kernel over a sampled prefix -> floor, K2g over the shadow -> survivors, exact re-score)
+    bool ts_stream = false;
+    if (use_cos && !a.force_exact && !a.no_fuse && idx->opt_two_stage == 1 && idx->dim % 64 == 0 && kprime <= orr::kSelWidth &&
+        (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
+        B <= orr::kMaxGemvScreenQ) {
         ORR_TRY(ensure_shadow(idx));
-        ts_small = idx->shadow_ready;
+        ts_stream = idx->shadow_ready;
     }
-    const bool approx_pass = use_mfma || ts_small;       // records carry no dot yet: K6 fills it in, exactly
+    const bool use_mfma = use_cos && !a.force_exact && (B >= mfma_min_batch || ts_stream) && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
+    const bool approx_pass = use_mfma;                   // records carry no dot yet: filled in exactly on the device
     a.used_mfma = approx_pass;
     a.used_fused = false;
     const bool direct_host = host_records && !approx_pass && rec_bytes <= (256u << 10);
@@ -1101,10 +1100,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     int32_t fused_sample_seg = 0;      // > 0: fused epilogue behind a sampled prefix of that many segments
     bool two_stage = false;            // plain-bf16 first stage over all rows + exact second stage
     bool records_have_dots = false;    // two-stage: exact dots copied from the survivors' buffer
-    bool ts_gemv = false;              // two-stage with the streaming screen for 5..8 queries
+    bool ts_gemv = false;              // two-stage with the streaming screen (1..8 queries)
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
-        if (B <= 64 || getenv("ORR_GEMM_KIND")) {
+        if (!ts_stream && (B <= 64 || getenv("ORR_GEMM_KIND"))) {
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
             d_dotf = idx->ws_dotf.as<float>();
         }
@@ -1113,28 +1112,22 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const bool ts_eligible = idx->opt_two_stage != 0 && !a.no_fuse && (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 &&
                                  std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
         static const int ts_min_batch = [] { const char *e = getenv("ORR_TS_MIN_BATCH"); return e ? atoi(e) : 5; }();
-        if (B < ts_min_batch || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form, 32 queries per launch (two launches at most)
-            for (int32_t b0 = 0; b0 < B; b0 += 32) {
-                const int32_t nq = std::min<int32_t>(32, B - b0);
-                Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);
-                HIP_TRY(orr::launch_gemv_mfma(d_q + (size_t)b0 * a.dim, nq, idx->d_emb, n, idx->dim, d_dotf + (size_t)b0 * n, n, s));
-            }
-        } else if (B <= orr::kMaxGemvScreenQ && idx->opt_two_stage == 1 && (ensure_shadow(idx), idx->shadow_ready)) {
-            // 5..8 queries: still HBM-bound, so no GEMM tile: the f32 streaming MFMA kernel over the prefix gives
-            // the floor and the shadow is streamed by the dot2 kernel (K2g) for all queries at once
+        if (ts_stream) {
+            // 1..8 queries: HBM-bound, so no GEMM tile: the f32 streaming MFMA kernel over the prefix gives the
+            // floor and the shadow is streamed by the dot2 kernel (K2g) for all queries at once
             ts_gemv = true;
             two_stage = true;
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
             fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
-            ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
-            d_dotf = idx->ws_dotf.as<float>();
-            {
-                Timed t(idx, "gemv_mfma_prefix", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
-                HIP_TRY(orr::launch_gemv_mfma(d_q, B, idx->d_emb, dotf_rows, idx->dim, d_dotf, dotf_rows, s));
-            }
             ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
             HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+        } else if (B < ts_min_batch || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form over all rows, 32 queries per launch
+            for (int32_t b0 = 0; b0 < B; b0 += 32) {
+                const int32_t nq = std::min<int32_t>(32, B - b0);
+                Timed t(idx, "gemv_mfma", 4.0 * (double)n * idx->dim + 4.0 * (double)nq * idx->dim + 4.0 * (double)nq * (double)n);
+                HIP_TRY(orr::launch_gemv_mfma(d_q + (size_t)b0 * a.dim, nq, idx->d_emb, n, idx->dim, d_dotf + (size_t)b0 * n, n, s));
+            }
         } else {
             static const bool f32_gemm = [] { const char *e = getenv("ORR_GEMM_KIND"); return e && strcmp(e, "f32") == 0; }();
             if (f32_gemm) {
@@ -1170,20 +1163,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const double eps_cos = bf16_split ? 3.1 * u16 + 3.06 * (double)idx->dim * u23
                                           : (2.0 * (double)idx->dim + 2.0) * u23;
         approx_eps = 0.7 * 1.01 * eps_cos + 1e-12;
-    } else if (ts_small) {
-        const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-        two_stage = true;
-        fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true);
-        dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
-        ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)dotf_rows));
-        d_dot = idx->ws_dot.as<double>();
-        {
-            Timed t(idx, "dot_exact_prefix", 4.0 * (double)dotf_rows * idx->dim + 4.0 * B * idx->dim + 8.0 * B * (double)dotf_rows);
-            HIP_TRY(orr::launch_dot_exact(idx->d_emb, dotf_rows, idx->dim, d_q, B, false, d_dot, dotf_rows, s));
-        }
-        ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
-        HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
-        approx_eps = 1e-12;                                  // the prefix scores are exact up to the selection form's few ulp
+        // streaming form: the prefix is scored by the plain-bf16 stream itself, so its floor carries that bound
+        if (ts_gemv) approx_eps = 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * u23) + 1e-12;
     } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
         d_dot = idx->ws_dot.as<double>();
@@ -1288,7 +1269,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     }
 
     // ---- per-query constants (exact normA needs the vectors on the host)
-    const bool batched_score = (B >= 4 || ts_small) && kprime <= orr::kSelWidth;     // per-row pieces once per batch
+    const bool batched_score = (B >= 4 || ts_stream) && kprime <= orr::kSelWidth;     // per-row pieces once per batch
     if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
     ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
@@ -1334,9 +1315,9 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * (size_t)B));
             ORR_TRY(idx->ws_fbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * kCap));
             d_tau = idx->ws_tau.as<unsigned long long>();
-            {
+            if (!ts_gemv) {
                 Timed t(idx, "fuse_select", (double)B * (double)dotf_rows * 28.0);
-                HIP_TRY(orr::launch_fuse_select(ts_small ? d_dot : nullptr, ts_small ? nullptr : d_dotf, dotf_rows, idx->d_norm_b,
+                HIP_TRY(orr::launch_fuse_select(nullptr, d_dotf, dotf_rows, idx->d_norm_b,
                                                 idx->d_created, d_rowc, kw, idx->ws_qc.as<orr::QueryConst>(), a.now_ticks,
                                                 dotf_rows, B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
                                                 lists_total, s));
@@ -1345,7 +1326,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             orr::FusedEpilogue epi;
             epi.count_planes = nullptr;
             epi.plane_stride = (n + 63) / 64 * 64;
-            if (kw.bitmaps && !ts_small && !ts_gemv) {
+            if (kw.bitmaps && !ts_gemv) {
                 Timed t(idx, "count_planes", 4.0 * orr::kCountPlanes * (double)((B + 31) / 32) * (double)n);
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
                 HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s));
@@ -1364,7 +1345,29 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 const double eps1 = 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * 1.1920928955078125e-07) + 1e-12;
                 ORR_TRY(idx->ws_tsL.reserve(sizeof(double) * (size_t)B));
                 ORR_TRY(idx->ws_tskey.reserve(sizeof(unsigned long long) * (size_t)B));
-                {
+                if (ts_gemv) {
+                    // the sample goes through the stream too: floor keys of 0 keep every sampled row, their
+                    // approximate keys are sorted in lists of 64 and the k-th best one per query is the floor's base
+                    const uint32_t cap_p = (uint32_t)dotf_rows;                 // a multiple of 4096
+                    const int32_t lists_p = (int32_t)(cap_p / orr::kSelWidth);
+                    ORR_TRY(idx->ws_pbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
+                    ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
+                    HIP_TRY(hipMemsetAsync(idx->ws_tskey.p, 0, sizeof(unsigned long long) * (size_t)B, s));
+                    orr::FusedEpilogue pre = epi;
+                    pre.tau = idx->ws_tskey.as<unsigned long long>();
+                    pre.buf = idx->ws_pbuf.as<orr::SelEntry>();
+                    pre.cap = cap_p;
+                    {
+                        Timed t(idx, "screen_gemv_prefix", 2.0 * (double)dotf_rows * idx->dim + 2.0 * (double)B * idx->dim);
+                        HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, std::min<int64_t>(dotf_rows, n), idx->dim, pre, s));
+                    }
+                    {
+                        Timed t(idx, "select_floor", 0.0);
+                        HIP_TRY(orr::launch_buffer_to_lists(pre.buf, pre.cnt, cap_p, B, 0, lists_p, idx->ws_psel.as<orr::SelEntry>(), s));
+                        HIP_TRY(orr::launch_select_final_sample(idx->ws_psel.as<orr::SelEntry>(), lists_p, lists_p, B, kth, d_tau, s));
+                    }
+                    HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
+                } else {
                     Timed t(idx, "select_floor", 0.0);
                     HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kth, d_tau, s));
                 }
@@ -1374,7 +1377,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                        idx->ws_fqf.as<float4>(), s));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (idx->opt_two_stage == 1) ORR_TRY(ensure_shadow(idx));
-                if (ts_small || ts_gemv) {
+                if (ts_gemv) {
                     Timed t(idx, "screen_gemv_bf16", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, n, idx->dim, epi, s));
                 } else if (idx->opt_two_stage == 1 && idx->shadow_ready) {
