@@ -860,7 +860,8 @@ int orr_index_view(orr_index *parent, orr_index **out)
     if (!parent->sealed) return fail(ORR_ESTATE, "orr_index_view: the index is not sealed");
     if (parent->is_view) return fail(ORR_EINVAL, "orr_index_view: take views of the owning index");
     HIP_TRY(hipSetDevice(parent->device));
-    if (parent->opt_two_stage == 1) ORR_TRY(ensure_shadow(parent));
+    // the shadow is shared, so it has to exist before the view does -- but only shards the two-stage pass applies to get one
+    if (parent->opt_two_stage == 1 && parent->n_rows >= 48 * (int64_t)orr::kSelSegRows) ORR_TRY(ensure_shadow(parent));
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
