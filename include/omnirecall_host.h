@@ -44,6 +44,16 @@ int64_t orrh_build_snippet(const uint8_t *content, int64_t content_len, int32_t 
 /* Math.Round(x, 4): banker's rounding of x*1e4 */
 double orrh_round4(double x);
 
+/* ---- the second consumer of the scores -----------------------
+ * ChatOrchestrationService.HasSufficientEvidence (ChatOrchestrationService.cs:58-65): at least
+ * max(1, minimum_citation_count) citations and one whose (4-decimal) score reaches
+ * max(0, minimum_strong_citation_score).  Returns 1 or 0. */
+int32_t orrh_has_sufficient_evidence(const double *citation_scores, int32_t n_citations, int32_t minimum_citation_count,
+                                     double minimum_strong_citation_score);
+/* The "score={c.Score:F4}" text of BuildGroundedPrompt (ChatOrchestrationService.cs:85) for a score that
+ * already went through Math.Round(x, 4); returns bytes written (no terminator) or -1. */
+int32_t orrh_format_score_f4(double rounded_score, char *out, int32_t out_cap);
+
 /* ---- store + service mirrors ------------------------------------------------
  * orrh_store mirrors the parts of InMemoryIngestionStore the path touches
  * (InMemoryIngestionStore.cs:11-25,50-76); orrh_service mirrors

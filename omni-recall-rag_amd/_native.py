@@ -101,6 +101,10 @@ host.orrh_build_snippet.restype = _i64
 host.orrh_build_snippet.argtypes = [C.c_char_p, _i64, _i32, _vp, _i64]
 host.orrh_round4.restype = _dbl
 host.orrh_round4.argtypes = [_dbl]
+host.orrh_has_sufficient_evidence.restype = _i32
+host.orrh_has_sufficient_evidence.argtypes = [_vp, _i32, _i32, _dbl]
+host.orrh_format_score_f4.restype = _i32
+host.orrh_format_score_f4.argtypes = [_dbl, _vp, _i32]
 
 host.orrh_last_error.restype = C.c_char_p
 host.orrh_store_create.restype = _vp
@@ -148,7 +152,7 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_view",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
-                         "orrh_round4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
+                         "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_service_create", "orrh_service_destroy",
                          "orrh_service_search_json", "orrh_service_stats", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",

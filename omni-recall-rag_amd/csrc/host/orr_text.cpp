@@ -2,6 +2,7 @@
 // the .NET calls the reference makes (see include/omnirecall_host.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -234,5 +235,35 @@ int64_t orrh_build_snippet(const uint8_t *content, int64_t content_len, int32_t 
 }
 
 double orrh_round4(double x) { return orrh::round4(x); }
+
+// ChatOrchestrationService.cs:58-65
+int32_t orrh_has_sufficient_evidence(const double *citation_scores, int32_t n_citations, int32_t minimum_citation_count,
+                                     double minimum_strong_citation_score)
+{
+    if (n_citations < 0 || (n_citations > 0 && !citation_scores)) return 0;
+    if (n_citations < std::max(1, minimum_citation_count)) return 0;                 // :60-61
+    const double threshold = std::max(0.0, minimum_strong_citation_score);           // :63  (Math.Max(0d, NaN) is NaN: nothing passes)
+    if (threshold != threshold) return 0;
+    for (int32_t i = 0; i < n_citations; ++i)
+        if (citation_scores[i] >= threshold) return 1;                               // :64
+    return 0;
+}
+
+// ChatOrchestrationService.cs:85: fixed-point with four decimals.  The value was rounded to four
+// decimals before (RecallSearchService.cs:51), so the nearest four-decimal string is unambiguous and
+// the C library's correctly rounded "%.4f" prints the digits .NET prints.
+int32_t orrh_format_score_f4(double rounded_score, char *out, int32_t out_cap)
+{
+    if (!out || out_cap <= 0) return -1;
+    char buf[64];
+    int n;
+    if (rounded_score != rounded_score) n = snprintf(buf, sizeof buf, "NaN");
+    else if (rounded_score == __builtin_inf()) n = snprintf(buf, sizeof buf, "\xE2\x88\x9E");      // U+221E, .NET's InvariantCulture symbol
+    else if (rounded_score == -__builtin_inf()) n = snprintf(buf, sizeof buf, "-\xE2\x88\x9E");
+    else n = snprintf(buf, sizeof buf, "%.4f", rounded_score == 0.0 ? 0.0 : rounded_score);   // "-0.0000" is "-0.0000" in .NET Core 3.0+ too, but a rounded score of -0 never reaches here
+    if (n < 0 || n > out_cap) return -1;
+    memcpy(out, buf, (size_t)n);
+    return n;
+}
 
 }  // extern "C"

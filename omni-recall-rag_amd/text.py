@@ -54,3 +54,22 @@ def build_snippet(content: Str, max_chars: int = 180) -> bytes:
 
 def round4(x: float) -> float:
     return N.host.orrh_round4(x)
+
+
+def has_sufficient_evidence(citation_scores, minimum_citation_count: int, minimum_strong_citation_score: float) -> bool:
+    """ChatOrchestrationService.HasSufficientEvidence (ChatOrchestrationService.cs:58-65) over the citations'
+    4-decimal scores."""
+    import numpy as np
+    sc = np.ascontiguousarray(citation_scores, dtype=np.float64)
+    return bool(N.host.orrh_has_sufficient_evidence(sc.ctypes.data if sc.size else None, int(sc.size),
+                                                    int(minimum_citation_count), float(minimum_strong_citation_score)))
+
+
+def format_score_f4(rounded_score: float) -> str:
+    """The `score={c.Score:F4}` text of the grounded prompt (ChatOrchestrationService.cs:85)."""
+    import ctypes as C
+    buf = C.create_string_buffer(64)
+    n = N.host.orrh_format_score_f4(float(rounded_score), C.cast(buf, C.c_void_p), 64)
+    if n < 0:
+        raise ValueError("orrh_format_score_f4 failed")
+    return buf.raw[:n].decode("utf-8")

@@ -244,3 +244,22 @@ def test_uploads_after_the_first_build_become_delta_shards():
         # restore for the second pass
         upload("old-03", base_time + 3 * 1000 + 1)
     store.close()
+
+
+def test_evidence_guard_and_prompt_score_text_consume_the_same_scores():
+    """ChatOrchestrationService only consumes the 4-decimal scores -- HasSufficientEvidence
+    (ChatOrchestrationService.cs:58-65, defaults MinimumCitationCount 1 / MinimumStrongCitationScore 0.25 in
+    appsettings.json:13-16) and the `score={c.Score:F4}` prompt text (:85)."""
+    P = pkg()
+    T = P.text
+    assert T.has_sufficient_evidence([0.31, 0.12], 1, 0.25) is True
+    assert T.has_sufficient_evidence([0.2499, 0.12], 1, 0.25) is False
+    assert T.has_sufficient_evidence([0.25], 1, 0.25) is True                  # >= threshold
+    assert T.has_sufficient_evidence([], 1, 0.25) is False
+    assert T.has_sufficient_evidence([0.9], 0, 0.25) is True                   # Math.Max(1, count)
+    assert T.has_sufficient_evidence([0.9], 2, 0.25) is False
+    assert T.has_sufficient_evidence([0.0], 1, -3.0) is True                   # Math.Max(0d, threshold)
+    assert T.has_sufficient_evidence([float("nan"), 0.1], 1, 0.25) is False
+    for raw, text in ((0.30000000000000004, "0.3000"), (0.9999999999999999, "1.0000"), (0.1, "0.1000"),
+                      (0.12345, "0.1234"), (0.12355, "0.1236"), (0.0, "0.0000"), (12.5, "12.5000")):
+        assert T.format_score_f4(T.round4(raw)) == text, raw
