@@ -245,6 +245,7 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload shape.
         traffic = None
         traffic_gemv = None
+        traffic_i8 = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if os.path.exists(pmc_path) and (rows, dim, B_local) == (1_000_000, 3072, 1):
             with open(pmc_path) as f:
@@ -253,16 +254,22 @@ def main():
                         traffic = kv["hbm_bytes_per_launch_corrected"]
                     if kname.startswith("orr::screen_gemv_bf16_kernel<1>") and "hbm_bytes_per_launch_corrected" in kv:
                         traffic_gemv = kv["hbm_bytes_per_launch_corrected"]
-        if "screen_gemv_bf16" in stats and stats["screen_gemv_bf16"]["launches"]:
-            # 1..4 queries per step with the bf16 shadow: the dominant kernel streams the shadow (2*N*D bytes)
-            sg = stats["screen_gemv_bf16"]
+                    if kname.startswith("orr::screen_gemv_i8_kernel<1, false>") and "hbm_bytes_per_launch_corrected" in kv:
+                        traffic_i8 = kv["hbm_bytes_per_launch_corrected"]
+        stream_name = "screen_gemv_i8" if stats.get("screen_gemv_i8", {}).get("launches") else "screen_gemv_bf16"
+        if stream_name in stats and stats[stream_name]["launches"]:
+            # 1..8 queries per step: the dominant kernel streams a shadow of the rows -- int8 (N*D + 12*N bytes, 1..4
+            # queries) or bf16 (2*N*D bytes); survivors are re-scored from the fp32 master
+            sg = stats[stream_name]
             avg_ms = sg["total_ms"] / sg["launches"]
             bytes_per_launch = sg["algo_bytes"] / sg["launches"]
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "screen_gemv_bf16", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_gemv,
-                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic_gemv else None,
+            roofline = {"bound": "hbm", "kernel": stream_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_gemv if stream_name == "screen_gemv_bf16" else traffic_i8,
+                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)",
                         "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
+            if roofline["traffic"] is None:
+                roofline["traffic_source"] = None
         elif dom["launches"]:
             avg_ms = dom["total_ms"] / dom["launches"]
             bytes_per_launch = dom["algo_bytes"] / dom["launches"]

@@ -201,7 +201,8 @@ int orr_index_view(orr_index *parent, orr_index **view);
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
  *   "two_stage"      0/1/2 (default 1): searches over >= 196,608 rows take ONE plain-bf16 product over all
- *                    rows (bound 2^-7 |q||e| on the dot; a stream for 1..8 queries, an MFMA GEMM for more),
+ *                    rows (bound 2^-7 |q||e| on the dot; a stream for 1..8 queries -- over an int8 shadow with a
+ *                    per-pair bound for 1..4 when dim % 128 == 0 and it fits, +25 % HBM -- an MFMA GEMM for more),
  *                    keep every (query,row) pair that could reach a lower
  *                    bound of the query's k-th best score, and re-score those in the reference arithmetic on
  *                    the device.  1: the product reads a bf16 shadow copy of the embeddings

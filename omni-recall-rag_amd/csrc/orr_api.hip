@@ -161,9 +161,11 @@ struct orr_index {
     int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
     DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
     bool shadow_ready = false, shadow_failed = false;
+    DevBuf emb_i8, i8_scale, i8_rel_err, i8_rel_hat;   // int8 shadow for the streaming screen of 1..4 queries (K2i)
+    bool i8_ready = false, i8_failed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -449,13 +451,15 @@ void orr_index_destroy(orr_index *idx)
         if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
     } else {
         idx->emb_shadow.p = nullptr; idx->emb_shadow.cap = 0;
+        for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat}) { b->p = nullptr; b->cap = 0; }
     }
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
-                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
+    idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release();
     idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release();
     if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -835,6 +839,36 @@ static int ensure_shadow(orr_index *idx)
     return ORR_OK;
 }
 
+// Int8 shadow for the streaming screen of 1..4 queries: a quarter of the master's bytes.  Built when it fits
+// WITH room left for the bf16 shadow the larger batches use (that one matters more); without it the small
+// batches stream the bf16 shadow.
+static int ensure_i8_shadow(orr_index *idx)
+{
+    if (idx->is_view || idx->i8_ready || idx->i8_failed || !idx->sealed || idx->n_rows <= 0 || idx->dim <= 0 || idx->dim % 128 != 0) return ORR_OK;
+    static const bool off = [] { const char *e = getenv("ORR_I8_SHADOW"); return e && atoi(e) == 0; }();
+    if (off) { idx->i8_failed = true; return ORR_OK; }
+    const size_t bytes = orr::i8_tiled_bytes(idx->n_rows, idx->dim);
+    const size_t reserve_bf16 = idx->shadow_ready ? 0 : orr::bf16_tiled_bytes(idx->n_rows, idx->dim);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + bytes / 8 + reserve_bf16 + reserve_bf16 / 8 + ((size_t)8 << 30)) {
+        idx->i8_failed = true;
+        return ORR_OK;
+    }
+    if (idx->emb_i8.reserve(bytes) != ORR_OK || idx->i8_scale.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK ||
+        idx->i8_rel_err.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK ||
+        idx->i8_rel_hat.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK) {
+        (void)hipGetLastError();
+        idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release();
+        idx->i8_failed = true;
+        return ORR_OK;
+    }
+    HIP_TRY(orr::launch_i8_shadow(idx->d_emb, idx->d_norm_b, idx->n_rows, idx->dim, idx->emb_i8.p, idx->i8_scale.as<float>(),
+                                  idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(), idx->stream));
+    HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->i8_ready = true;
+    return ORR_OK;
+}
+
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
 {
     if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
@@ -861,7 +895,10 @@ int orr_index_view(orr_index *parent, orr_index **out)
     if (parent->is_view) return fail(ORR_EINVAL, "orr_index_view: take views of the owning index");
     HIP_TRY(hipSetDevice(parent->device));
     // the shadow is shared, so it has to exist before the view does -- but only shards the two-stage pass applies to get one
-    if (parent->opt_two_stage == 1 && parent->n_rows >= 48 * (int64_t)orr::kSelSegRows) ORR_TRY(ensure_shadow(parent));
+    if (parent->opt_two_stage == 1 && parent->n_rows >= 48 * (int64_t)orr::kSelSegRows) {
+        ORR_TRY(ensure_shadow(parent));
+        ORR_TRY(ensure_i8_shadow(parent));
+    }
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
@@ -874,6 +911,9 @@ int orr_index_view(orr_index *parent, orr_index **out)
     v->opt_fuse_epilogue = parent->opt_fuse_epilogue; v->opt_two_stage = parent->opt_two_stage;
     v->emb_shadow.p = parent->emb_shadow.p; v->emb_shadow.cap = 0;           // borrowed, never freed here
     v->shadow_ready = parent->shadow_ready; v->shadow_failed = !parent->shadow_ready;
+    v->emb_i8.p = parent->emb_i8.p; v->i8_scale.p = parent->i8_scale.p; v->i8_rel_err.p = parent->i8_rel_err.p;
+    v->i8_rel_hat.p = parent->i8_rel_hat.p;                                   // borrowed as well
+    v->i8_ready = parent->i8_ready; v->i8_failed = !parent->i8_ready;
     if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&v->stream_kw, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_inputs, hipEventDisableTiming) != hipSuccess ||
@@ -1036,12 +1076,14 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
     // 1..8 queries over a large shard with the bf16 shadow in place: the streaming form of the two-stage pass
     // (f32 streaming MFMA kernel over a sampled prefix -> floor, K2g over the shadow -> survivors, exact re-score)
-    bool ts_stream = false;
+    bool ts_stream = false, ts_i8 = false;
     if (use_cos && !a.force_exact && !a.no_fuse && idx->opt_two_stage == 1 && idx->dim % 64 == 0 && kprime <= orr::kSelWidth &&
         (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
         B <= orr::kMaxGemvScreenQ) {
-        ORR_TRY(ensure_shadow(idx));
-        ts_stream = idx->shadow_ready;
+        if (B <= orr::kMaxI8ScreenQ) ORR_TRY(ensure_i8_shadow(idx));
+        ts_i8 = B <= orr::kMaxI8ScreenQ && idx->i8_ready;
+        if (!ts_i8) ORR_TRY(ensure_shadow(idx));
+        ts_stream = ts_i8 || idx->shadow_ready;
     }
     const bool use_mfma = use_cos && !a.force_exact && (B >= mfma_min_batch || ts_stream) && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
     const bool approx_pass = use_mfma;                   // records carry no dot yet: filled in exactly on the device
@@ -1121,8 +1163,15 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
             fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
-            ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
-            HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+            if (ts_i8) {
+                ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
+                ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
+                ORR_TRY(idx->ws_q8err.reserve(sizeof(double) * (size_t)B));
+                HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s));
+            } else {
+                ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
+                HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+            }
         } else if (B < ts_min_batch || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form over all rows, 32 queries per launch
             for (int32_t b0 = 0; b0 < B; b0 += 32) {
                 const int32_t nq = std::min<int32_t>(32, B - b0);
@@ -1166,6 +1215,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         approx_eps = 0.7 * 1.01 * eps_cos + 1e-12;
         // streaming form: the prefix is scored by the plain-bf16 stream itself, so its floor carries that bound
         if (ts_gemv) approx_eps = 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * u23) + 1e-12;
+        if (ts_i8) approx_eps = 1e-12;           // int8 form: the sample's keys are already lower bounds
     } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
         d_dot = idx->ws_dot.as<double>();
@@ -1343,7 +1393,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 // exactly; the best k' of them become the records
                 const int32_t kth = std::max<int32_t>(1, a.topk);
                 // plain bf16: (1 + u)^2 - 1 per product with u = 2^-8, D additions charged 2^-23 each
-                const double eps1 = 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * 1.1920928955078125e-07) + 1e-12;
+                const double eps1 = ts_i8 ? 0.0     // int8 form: the per-pair bound is added inside the kernel
+                                          : 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * 1.1920928955078125e-07) + 1e-12;
                 ORR_TRY(idx->ws_tsL.reserve(sizeof(double) * (size_t)B));
                 ORR_TRY(idx->ws_tskey.reserve(sizeof(unsigned long long) * (size_t)B));
                 if (ts_gemv) {
@@ -1359,8 +1410,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                     pre.buf = idx->ws_pbuf.as<orr::SelEntry>();
                     pre.cap = cap_p;
                     {
-                        Timed t(idx, "screen_gemv_prefix", 2.0 * (double)dotf_rows * idx->dim + 2.0 * (double)B * idx->dim);
-                        HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, std::min<int64_t>(dotf_rows, n), idx->dim, pre, s));
+                        Timed t(idx, "screen_gemv_prefix", (ts_i8 ? 1.0 : 2.0) * (double)dotf_rows * idx->dim + 2.0 * (double)B * idx->dim);
+                        if (ts_i8)
+                            HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
+                                                               idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(),
+                                                               std::min<int64_t>(dotf_rows, n), idx->dim, pre, true, s));
+                        else
+                            HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, std::min<int64_t>(dotf_rows, n), idx->dim, pre, s));
                     }
                     {
                         Timed t(idx, "select_floor", 0.0);
@@ -1377,8 +1433,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
                                                        idx->ws_fqf.as<float4>(), s));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
-                if (idx->opt_two_stage == 1) ORR_TRY(ensure_shadow(idx));
-                if (ts_gemv) {
+                if (idx->opt_two_stage == 1 && !ts_gemv) ORR_TRY(ensure_shadow(idx));
+                if (ts_i8) {
+                    Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 12.0 * (double)n + 2.0 * (double)B * idx->dim);
+                    HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
+                                                       idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(), n,
+                                                       idx->dim, epi, false, s));
+                } else if (ts_gemv) {
                     Timed t(idx, "screen_gemv_bf16", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, n, idx->dim, epi, s));
                 } else if (idx->opt_two_stage == 1 && idx->shadow_ready) {

@@ -14,6 +14,7 @@ constexpr int kSelSegRows = 4096;    // rows one workgroup of fuse_select scans
 constexpr int kMaxExactQ = 8;        // queries one launch of the exact dot kernel carries
 constexpr int kMaxScanTerms = 64;    // query terms one launch of the keyword scan carries
 constexpr int kMaxGemvScreenQ = 8;   // queries one launch of the streaming screen (K2g) carries
+constexpr int kMaxI8ScreenQ = 4;     // ... of its int8 form (K2i): two accumulators per query and row
 constexpr int kCountPlanes = 4;      // bit planes of the per-(query,row) keyword match count (saturates at 15)
 
 // One selection entry: `key` orders scores (see score_key in the .hip), `pos` is the
@@ -153,6 +154,15 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
 // K2g: the screening pass for 1..kMaxGemvScreenQ queries as a stream over the tiled shadow (no matrix core).
 hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_shadow, int64_t n_rows, int32_t D,
                                    const FusedEpilogue &epi, hipStream_t s);
+// K2i: the streaming screen over an INT8 shadow (per-row scale, two-level int8 queries, exact integer dots,
+// a per-pair Cauchy-Schwarz bound from the quantisation norms) -- see orr_screen.hip.  D % 128 == 0.
+size_t i8_tiled_bytes(int64_t n_rows, int32_t D);
+hipError_t launch_i8_shadow(const float *E, const double *norm_b, int64_t n_rows, int32_t D, void *tiled, float *scale,
+                            float *rel_err, float *rel_hat, hipStream_t s);
+hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s);
+hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double *err2, int32_t B, const void *tiled,
+                                 const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, int32_t D,
+                                 const FusedEpilogue &epi, bool lower_bound, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
 hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
                                   unsigned long long *floor_key, double *L_out, hipStream_t s);

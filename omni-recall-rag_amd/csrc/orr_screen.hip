@@ -266,6 +266,223 @@ __global__ __launch_bounds__(256, 2) void screen_gemv_bf16_kernel(const __bf16 *
     }
 }
 
+// ---------------------------------------------------------------------------
+// K2i: the streaming screen on an INT8 shadow (1..8 queries): a quarter of the fp32 bytes.
+//
+// Row r is stored as ie[r][k] = rint(e[r][k] / se_r), se_r = max_k |e[r][k]| / 127, in the same tiled
+// layout (64 bytes = 64 k per image row, chunk c of 16 bytes in slot c ^ ((row >> 2) & 3)).  A query is
+// split into TWO int8 components, q^ = s1 (iq1 + iq2 / 254) with iq1 = rint(q / s1), s1 = max|q| / 127,
+// iq2 = rint((q - s1 iq1) / (s1 / 254)), so its quantisation error is ~254 times smaller than the row's.
+// v_dot4c_i32_i8 sums exactly (|sum| <= 3072 * 127^2 < 2^31), hence  dot^ = s1 se_r (I1 + I2 / 254)  is
+// the exact dot of the two quantised vectors and
+//     |q.e - dot^|  <=  |q| |e - e^|  +  |q - q^| |e^|                       (Cauchy-Schwarz)
+// with BOTH norms of differences computed when the vectors are quantised (fp64, rounded up): the bound is
+// per (query,row) and data dependent -- about 0.8 % of |q||e| for Gaussian rows, everything for a row
+// whose quantisation is poor (such a row simply always survives).  LOWER = true subtracts the bound
+// (keys of the sampled prefix: their k-th best is a lower bound of the k-th best exact score), false adds
+// it (screen: a pair is dropped only if even its upper bound stays below the floor).
+// ---------------------------------------------------------------------------
+struct I8Rows {
+    const int8_t *tiled;        // [tiles][D/64][256][64]
+    const float *scale;         // se_r
+    const float *rel_err;       // |e - e^| / sqrt(normB), rounded up (0 where normB <= 0)
+    const float *rel_hat;       // |e^| / sqrt(normB), rounded up
+};
+struct I8Queries {
+    const int8_t *q1, *q2;      // [B][D]
+    const float *s1;            // [B]
+    const double *err2;         // [B] |q - q^|^2
+};
+
+template <int NQ, bool LOWER>
+__global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int32_t D, I8Rows R, int64_t n_units, int64_t n_rows,
+                                                                FusedEpilogue epi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lq[];     // [2][NQ][D] int8
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid * 16; i < NQ * D; i += 256 * 16) {
+        *reinterpret_cast<uint4 *>(lq + i) = *reinterpret_cast<const uint4 *>(Q.q1 + i);
+        *reinterpret_cast<uint4 *>(lq + NQ * D + i) = *reinterpret_cast<const uint4 *>(Q.q2 + i);
+    }
+    __syncthreads();
+    const int c = (lane & 3) ^ ((lane >> 4) & 3);
+    const int KT = D / 64;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < n_units; u += (int64_t)gridDim.x * 4) {
+        const int8_t *base = R.tiled + ((u >> 1) * KT) * (int64_t)(256 * 64) + (u & 1) * (128 * 64) + lane * 16;
+        int a1[NQ][8], a2[NQ][8];
+#pragma unroll
+        for (int b = 0; b < NQ; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a1[b][j] = 0; a2[b][j] = 0; }
+        i32x4 s0[8], s1[8];
+#define ORR_LOAD8(st, kt) { \
+        const int8_t *p_ = base + (int64_t)(kt) * (256 * 64); \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) st[j] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p_ + j * 1024)); }
+#define ORR_DOT8(st, kt) { \
+        _Pragma("unroll") for (int b = 0; b < NQ; ++b) { \
+            const i32x4 qa = *reinterpret_cast<const i32x4 *>(lq + (size_t)b * D + (kt) * 64 + c * 16); \
+            const i32x4 qb = *reinterpret_cast<const i32x4 *>(lq + (size_t)(NQ + b) * D + (kt) * 64 + c * 16); \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
+                _Pragma("unroll") for (int w = 0; w < 4; ++w) { \
+                    a1[b][j] = __builtin_amdgcn_sdot4(st[j][w], qa[w], a1[b][j], false); \
+                    a2[b][j] = __builtin_amdgcn_sdot4(st[j][w], qb[w], a2[b][j], false); } } } }
+        ORR_LOAD8(s0, 0)
+        for (int kt = 0; kt < KT; kt += 2) {                                // D % 128 == 0
+            ORR_LOAD8(s1, kt + 1)
+            ORR_DOT8(s0, kt)
+            ORR_LOAD8(s0, (kt + 2 < KT ? kt + 2 : KT - 1))                   // clamped, never branched around
+            ORR_DOT8(s1, kt + 1)
+        }
+#undef ORR_DOT8
+#undef ORR_LOAD8
+#pragma unroll
+        for (int b = 0; b < NQ; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a1[b][j] += __shfl_xor(a1[b][j], 1, 64); a1[b][j] += __shfl_xor(a1[b][j], 2, 64);
+                a2[b][j] += __shfl_xor(a2[b][j], 1, 64); a2[b][j] += __shfl_xor(a2[b][j], 2, 64);
+            }
+        const int sl = lane & 3;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int64_t row = (u >> 1) * kScBN + (u & 1) * 128 + 16 * (jj * 4 + sl) + (lane >> 2);
+            if (row >= n_rows) continue;
+            const double2 rc = epi.rowc[row];
+            const double se = (double)R.scale[row], re = (double)R.rel_err[row], rh = (double)R.rel_hat[row];
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) {
+                const int i1 = sl == 0 ? a1[b][jj * 4] : sl == 1 ? a1[b][jj * 4 + 1] : sl == 2 ? a1[b][jj * 4 + 2] : a1[b][jj * 4 + 3];
+                const int i2 = sl == 0 ? a2[b][jj * 4] : sl == 1 ? a2[b][jj * 4 + 1] : sl == 2 ? a2[b][jj * 4 + 2] : a2[b][jj * 4 + 3];
+                const QueryConst qc = epi.qc[b];
+                const double dot = se * (double)Q.s1[b] * ((double)i1 + (double)i2 * (1.0 / 254.0));
+                // |cos error| <= (|q|/sqrt(normA)) re + (|q - q^|/sqrt(normA)) rh ; the first factor is 1 up to 2^-23
+                double err = 0.0;
+                // ... plus 2^-23: the reference sums fp32-ROUNDED products (RecallSearchService.cs:79), the bound above is
+                // about the real dot
+                if (qc.use_cos) err = 0.7 * 1.000001 * (re * 1.0000003 + sqrt(Q.err2[b]) * qc.inv_sqrt_na * rh + 1.2e-7) + 1e-9;
+                const uint32_t mm = qc.n_terms > 0 ? kw_matches(epi.kw, b, (uint32_t)row) : 0u;
+                const double sc = fused_score_fast(dot, rc.x, rc.y, mm, qc) + (LOWER ? -err : err);
+                unsigned long long key = score_key(sc);
+                if (!(fabs(sc) <= 1.7976931348623157e308)) key = LOWER ? 1ull : ~0ull;     // non-finite: no floor from it / never dropped
+                if (key > epi.tau[b]) {
+                    const uint32_t slot = atomicAdd(&epi.cnt[b], 1u);
+                    if (slot < epi.cap) {
+                        SelEntry en;
+                        en.key = key; en.pos = (uint32_t)row; en.pad = 0;
+                        epi.buf[(int64_t)b * epi.cap + slot] = en;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One wave per row: scale, int8 image (tiled, swizzled), and the two relative norms the bound needs.
+__global__ __launch_bounds__(256) void i8_shadow_kernel(const float *__restrict__ E, const double *__restrict__ norm_b, int64_t n_rows,
+                                                        int64_t rows_padded, int32_t D, int8_t *__restrict__ out,
+                                                        float *__restrict__ scale, float *__restrict__ rel_err, float *__restrict__ rel_hat)
+{
+    const int lane = threadIdx.x & 63;
+    const int KT = D / 64;
+    for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < rows_padded; row += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t tile = row >> 8;
+        const int rr = (int)(row & 255);
+        int8_t *dst = out + (tile * KT) * (int64_t)(256 * 64) + rr * 64;
+        if (row >= n_rows) {                                                // padding rows of the last tile
+            for (int k = lane * 4; k < D; k += 256)
+                *reinterpret_cast<uint32_t *>(dst + (int64_t)(k >> 6) * (256 * 64) + ((((k & 63) >> 4) ^ ((rr >> 2) & 3)) << 4) + (k & 15)) = 0u;
+            continue;
+        }
+        const float *src = E + row * (int64_t)D;
+        float mx = 0.f;
+        bool bad = false;
+        for (int k = lane * 4; k < D; k += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + k);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            bad = bad || !(fabsf(v.x) <= 3.4028234663852886e38f) || !(fabsf(v.y) <= 3.4028234663852886e38f) ||
+                  !(fabsf(v.z) <= 3.4028234663852886e38f) || !(fabsf(v.w) <= 3.4028234663852886e38f);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        bad = __any(bad);
+        const float se = (bad || mx == 0.f) ? 0.f : mx / 127.f;
+        const float inv = se > 0.f ? 1.f / se : 0.f;
+        double d2 = 0.0, h2 = 0.0;
+        for (int k = lane * 4; k < D; k += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + k);
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            uint32_t packed = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int q = se > 0.f ? __float2int_rn(x[e] * inv) : 0;
+                q = q > 127 ? 127 : (q < -127 ? -127 : q);
+                const double hat = (double)se * (double)q;
+                const double dl = (double)x[e] - hat;
+                d2 += dl * dl;
+                h2 += hat * hat;
+                packed |= ((uint32_t)(uint8_t)(int8_t)q) << (8 * e);
+            }
+            *reinterpret_cast<uint32_t *>(dst + (int64_t)(k >> 6) * (256 * 64) + ((((k & 63) >> 4) ^ ((rr >> 2) & 3)) << 4) + (k & 15)) = packed;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { d2 += __shfl_xor(d2, d, 64); h2 += __shfl_xor(h2, d, 64); }
+        if (lane == 0) {
+            const double nb = norm_b[row];
+            scale[row] = se;
+            if (!(nb > 0.0)) { rel_err[row] = 0.f; rel_hat[row] = 0.f; }     // cosine is 0 for this row whatever the dot (:84)
+            else if (bad) { rel_err[row] = __builtin_huge_valf(); rel_hat[row] = 0.f; }   // never screened out
+            else {
+                rel_err[row] = __double2float_ru(sqrt(d2 / nb) * 1.000001);
+                rel_hat[row] = __double2float_ru(sqrt(h2 / nb) * 1.000001);
+            }
+        }
+    }
+}
+
+// Two-level int8 image of up to 8 queries (one workgroup each) and |q - q^|^2.
+__global__ __launch_bounds__(256) void i8_queries_kernel(const float *__restrict__ Qf, int32_t D, int8_t *__restrict__ q1, int8_t *__restrict__ q2,
+                                                         float *__restrict__ s1_out, double *__restrict__ err2_out)
+{
+    __shared__ float red_f[4];
+    __shared__ double red_d[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *q = Qf + (int64_t)b * D;
+    float mx = 0.f;
+    bool bad = false;
+    for (int k = tid; k < D; k += 256) { const float v = q[k]; mx = fmaxf(mx, fabsf(v)); bad = bad || !(fabsf(v) <= 3.4028234663852886e38f); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if (lane == 0) red_f[wave] = (__any(bad) ? __builtin_huge_valf() : mx);
+    bad = __any(bad);
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
+    const bool usable = mx > 0.f && mx <= 3.4028234663852886e38f;
+    const float s1 = usable ? mx / 127.f : 0.f, s2 = s1 / 254.f;
+    double e2 = 0.0;
+    for (int k = tid; k < D; k += 256) {
+        const float v = q[k];
+        int a = usable ? __float2int_rn(v / s1) : 0;
+        a = a > 127 ? 127 : (a < -127 ? -127 : a);
+        const double r = (double)v - (double)s1 * (double)a;
+        int c2 = (usable && s2 > 0.f) ? __double2int_rn(r / (double)s2) : 0;
+        c2 = c2 > 127 ? 127 : (c2 < -127 ? -127 : c2);
+        const double dl = r - (double)s1 * ((double)c2 / 254.0);               // q^ = s1 (a + c2 / 254)
+        e2 += usable ? dl * dl : (double)v * (double)v;
+        q1[(int64_t)b * D + k] = (int8_t)a;
+        q2[(int64_t)b * D + k] = (int8_t)c2;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) e2 += __shfl_xor(e2, d, 64);
+    if (lane == 0) red_d[wave] = e2;
+    __syncthreads();
+    if (tid == 0) {
+        s1_out[b] = s1;
+        const double tot = red_d[0] + red_d[1] + red_d[2] + red_d[3];
+        err2_out[b] = (mx <= 3.4028234663852886e38f) ? tot * 1.000001 : __builtin_huge_val();
+    }
+}
+
 // Tiled, pre-swizzled bf16 image of a row-major fp32 matrix X[n_rows][D] (see the header): output
 // chunk o (16 bytes) = 8 consecutive k of one row.  rows_padded = n_tiles * 256.
 __global__ __launch_bounds__(256) void bf16_tiled_kernel(const float *__restrict__ X, int64_t n_rows, int32_t D, int64_t n_chunks,
@@ -310,6 +527,59 @@ hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *ou
     const int64_t n_chunks = (int64_t)(bf16_tiled_bytes(n_rows, D) / 16);
     const int64_t blocks = std::min<int64_t>((n_chunks + 255) / 256, 65536);
     hipLaunchKernelGGL(bf16_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, n_rows, D, n_chunks, static_cast<__bf16 *>(out));
+    return hipGetLastError();
+}
+
+size_t i8_tiled_bytes(int64_t n_rows, int32_t D)
+{
+    return (size_t)((n_rows + kScBN - 1) / kScBN) * kScBN * (size_t)D;
+}
+
+// Int8 shadow of the sealed rows (K2i): image + per-row scale and relative norms.  D % 128 == 0.
+hipError_t launch_i8_shadow(const float *E, const double *norm_b, int64_t n_rows, int32_t D, void *tiled, float *scale,
+                            float *rel_err, float *rel_hat, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    if (D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    const int64_t rows_padded = (n_rows + kScBN - 1) / kScBN * kScBN;
+    const int64_t blocks = std::min<int64_t>((rows_padded + 3) / 4, 65536);
+    hipLaunchKernelGGL(i8_shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, s, E, norm_b, n_rows, rows_padded, D,
+                       static_cast<int8_t *>(tiled), scale, rel_err, rel_hat);
+    return hipGetLastError();
+}
+
+// ws: [q1 B*D][q2 B*D] int8, s1 [B] float, err2 [B] double -- see I8Queries.
+hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    int8_t *q1 = static_cast<int8_t *>(q12);
+    hipLaunchKernelGGL(i8_queries_kernel, dim3((unsigned)B), dim3(256), 0, s, Q, D, q1, q1 + (size_t)B * D, s1, err2);
+    return hipGetLastError();
+}
+
+// The streaming screen over the int8 shadow.  lower_bound = true: keys are score - bound (prefix floor).
+hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double *err2, int32_t B, const void *tiled,
+                                 const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, int32_t D,
+                                 const FusedEpilogue &epi, bool lower_bound, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (B > kMaxI8ScreenQ || D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    const int64_t n_units = ((n_rows + kScBN - 1) / kScBN) * 2;
+    const int64_t blocks = std::min<int64_t>((n_units + 3) / 4, 512);
+    const size_t lds = 2 * (size_t)B * (size_t)D;
+    if (lds > 65536) return hipErrorInvalidValue;
+    const int8_t *q1 = static_cast<const int8_t *>(q12);
+    I8Queries Qd{q1, q1 + (size_t)B * D, s1, err2};
+    I8Rows Rd{static_cast<const int8_t *>(tiled), scale, rel_err, rel_hat};
+#define ORR_I8(NQ) do { if (lower_bound) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, epi); \
+                        else hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, false>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, epi); } while (0)
+    switch (B) {
+    case 1: ORR_I8(1); break;
+    case 2: ORR_I8(2); break;
+    case 3: ORR_I8(3); break;
+    default: ORR_I8(4); break;
+    }
+#undef ORR_I8
     return hipGetLastError();
 }
 
