@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (no sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0       # dense int8 MFMA peak (no sparsity)
 
 
 def parse_args():
@@ -278,15 +279,18 @@ def main():
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                         "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
-        elif "screen_bf16_fused" in stats and stats["screen_bf16_fused"]["launches"]:
-            # batched runs (--batch > 64): the dominant kernel is the screening GEMM of the two-stage pass,
-            # 2*B*N*D bf16 flop per launch against the dense bf16 MFMA peak (MI355X_MICROARCH.md)
-            sc = stats["screen_bf16_fused"]
+        elif any(stats.get(k, {}).get("launches") for k in ("screen_i8_fused", "screen_bf16_fused")):
+            # batched runs (--batch > 8): the dominant kernel is the screening GEMM of the two-stage pass, 2*B*N*D
+            # multiply-adds per launch against the dense MFMA peak of its type (MI355X_MICROARCH.md): int8 on the
+            # int8 shadow (5 POP/s), bf16 otherwise (2.5 PFLOP/s)
+            gname = "screen_i8_fused" if stats.get("screen_i8_fused", {}).get("launches") else "screen_bf16_fused"
+            sc = stats[gname]
             avg_ms = sc["total_ms"] / sc["launches"]
             flops = 2.0 * (world * B_local) * rows * dim
             achieved = flops / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "screen_bf16_fused", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+            peak = MFMA_I8_PEAK_TOPS if gname == "screen_i8_fused" else MFMA_BF16_PEAK_TFLOPS
+            roofline = {"bound": "mfma", "kernel": gname, "achieved": achieved, "peak": peak,
+                        "unit": "TOP/s" if gname == "screen_i8_fused" else "TFLOP/s", "frac": achieved / peak, "traffic": None,
                         "avg_launch_ms": avg_ms, "algo_flops_per_launch": flops}
         out = {
             "metric": "queries/sec at top-k=10 over N x 3072-d chunks",

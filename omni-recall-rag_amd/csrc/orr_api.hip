@@ -161,7 +161,7 @@ struct orr_index {
     int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
     DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
     bool shadow_ready = false, shadow_failed = false;
-    DevBuf emb_i8, i8_scale, i8_rel_err, i8_rel_hat;   // int8 shadow for the streaming screen of 1..4 queries (K2i)
+    DevBuf emb_i8, i8_scale, i8_rel_err, i8_rel_hat, i8_rowf;   // int8 shadow: streaming screen of 1..4 queries (K2i), screening GEMM (K2j)
     bool i8_ready = false, i8_failed = false;
 
     // search workspace
@@ -451,7 +451,7 @@ void orr_index_destroy(orr_index *idx)
         if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
     } else {
         idx->emb_shadow.p = nullptr; idx->emb_shadow.cap = 0;
-        for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat}) { b->p = nullptr; b->cap = 0; }
+        for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat, &idx->i8_rowf}) { b->p = nullptr; b->cap = 0; }
     }
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
@@ -459,7 +459,7 @@ void orr_index_destroy(orr_index *idx)
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
-    idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release();
+    idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
     idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release();
     if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -839,31 +839,33 @@ static int ensure_shadow(orr_index *idx)
     return ORR_OK;
 }
 
-// Int8 shadow for the streaming screen of 1..4 queries: a quarter of the master's bytes.  Built when it fits
-// WITH room left for the bf16 shadow the larger batches use (that one matters more); without it the small
-// batches stream the bf16 shadow.
+// Int8 shadow (a quarter of the master's bytes): operand of the streaming screen of 1..4 queries (K2i) and of
+// the screening GEMM of larger batches (K2j).  Where it exists the bf16 shadow is only built for what it
+// does not cover (5..8 queries, dimensions that are not a multiple of 128).
 static int ensure_i8_shadow(orr_index *idx)
 {
     if (idx->is_view || idx->i8_ready || idx->i8_failed || !idx->sealed || idx->n_rows <= 0 || idx->dim <= 0 || idx->dim % 128 != 0) return ORR_OK;
     static const bool off = [] { const char *e = getenv("ORR_I8_SHADOW"); return e && atoi(e) == 0; }();
     if (off) { idx->i8_failed = true; return ORR_OK; }
-    const size_t bytes = orr::i8_tiled_bytes(idx->n_rows, idx->dim);
-    const size_t reserve_bf16 = idx->shadow_ready ? 0 : orr::bf16_tiled_bytes(idx->n_rows, idx->dim);
+    const size_t bytes = orr::i8_tiled_bytes(idx->n_rows, idx->dim) + 28 * (size_t)idx->n_rows;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + bytes / 8 + reserve_bf16 + reserve_bf16 / 8 + ((size_t)8 << 30)) {
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + bytes / 8 + ((size_t)8 << 30)) {   // keep 8 GiB for workspaces
         idx->i8_failed = true;
         return ORR_OK;
     }
-    if (idx->emb_i8.reserve(bytes) != ORR_OK || idx->i8_scale.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK ||
+    if (idx->emb_i8.reserve(orr::i8_tiled_bytes(idx->n_rows, idx->dim)) != ORR_OK || idx->i8_scale.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK ||
         idx->i8_rel_err.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK ||
-        idx->i8_rel_hat.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK) {
+        idx->i8_rel_hat.reserve(sizeof(float) * (size_t)idx->n_rows) != ORR_OK ||
+        idx->i8_rowf.reserve(sizeof(float4) * (size_t)idx->n_rows) != ORR_OK) {
         (void)hipGetLastError();
-        idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release();
+        idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
         idx->i8_failed = true;
         return ORR_OK;
     }
     HIP_TRY(orr::launch_i8_shadow(idx->d_emb, idx->d_norm_b, idx->n_rows, idx->dim, idx->emb_i8.p, idx->i8_scale.as<float>(),
                                   idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(), idx->stream));
+    HIP_TRY(orr::launch_i8_rowf(idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(), idx->n_rows,
+                                idx->i8_rowf.as<float4>(), idx->stream));
     HIP_TRY(hipStreamSynchronize(idx->stream));
     idx->i8_ready = true;
     return ORR_OK;
@@ -896,8 +898,8 @@ int orr_index_view(orr_index *parent, orr_index **out)
     HIP_TRY(hipSetDevice(parent->device));
     // the shadow is shared, so it has to exist before the view does -- but only shards the two-stage pass applies to get one
     if (parent->opt_two_stage == 1 && parent->n_rows >= 48 * (int64_t)orr::kSelSegRows) {
-        ORR_TRY(ensure_shadow(parent));
         ORR_TRY(ensure_i8_shadow(parent));
+        if (!parent->i8_ready) ORR_TRY(ensure_shadow(parent));
     }
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
@@ -912,7 +914,7 @@ int orr_index_view(orr_index *parent, orr_index **out)
     v->emb_shadow.p = parent->emb_shadow.p; v->emb_shadow.cap = 0;           // borrowed, never freed here
     v->shadow_ready = parent->shadow_ready; v->shadow_failed = !parent->shadow_ready;
     v->emb_i8.p = parent->emb_i8.p; v->i8_scale.p = parent->i8_scale.p; v->i8_rel_err.p = parent->i8_rel_err.p;
-    v->i8_rel_hat.p = parent->i8_rel_hat.p;                                   // borrowed as well
+    v->i8_rel_hat.p = parent->i8_rel_hat.p; v->i8_rowf.p = parent->i8_rowf.p;   // borrowed as well
     v->i8_ready = parent->i8_ready; v->i8_failed = !parent->i8_ready;
     if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&v->stream_kw, hipStreamNonBlocking) != hipSuccess ||
@@ -1374,7 +1376,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                 lists_total, s));
             }
             ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * (size_t)B));
-            orr::FusedEpilogue epi;
+            orr::FusedEpilogue epi{};
             epi.count_planes = nullptr;
             epi.plane_stride = (n + 63) / 64 * 64;
             if (kw.bitmaps && !ts_gemv) {
@@ -1393,7 +1395,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 // exactly; the best k' of them become the records
                 const int32_t kth = std::max<int32_t>(1, a.topk);
                 // plain bf16: (1 + u)^2 - 1 per product with u = 2^-8, D additions charged 2^-23 each
-                const double eps1 = ts_i8 ? 0.0     // int8 form: the per-pair bound is added inside the kernel
+                const bool i8_gemm_planned = idx->opt_two_stage == 1 && !ts_gemv && idx->dim % 128 == 0 &&
+                                             (idx->i8_ready || (!idx->i8_failed && !idx->is_view));
+                if (i8_gemm_planned) ORR_TRY(ensure_i8_shadow(idx));
+                const double eps1 = (ts_i8 || (i8_gemm_planned && idx->i8_ready)) ? 0.0     // int8 forms: the per-pair bound is added inside the kernel
                                           : 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * 1.1920928955078125e-07) + 1e-12;
                 ORR_TRY(idx->ws_tsL.reserve(sizeof(double) * (size_t)B));
                 ORR_TRY(idx->ws_tskey.reserve(sizeof(unsigned long long) * (size_t)B));
@@ -1430,11 +1435,33 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 }
                 HIP_TRY(orr::launch_two_stage_floor(d_tau, B, approx_eps, eps1, idx->ws_tskey.as<unsigned long long>(),
                                                     idx->ws_tsL.as<double>(), s));
+                // the screening GEMM runs on the int8 shadow where there is one (K2j), else on the bf16 shadow (K2c),
+                // else it converts the fp32 rows itself
+                bool gemm_i8 = false;
+                if (idx->opt_two_stage == 1 && !ts_gemv) {
+                    ORR_TRY(ensure_i8_shadow(idx));
+                    gemm_i8 = idx->i8_ready;
+                    if (!gemm_i8) ORR_TRY(ensure_shadow(idx));
+                }
+                if (gemm_i8) {
+                    ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
+                    ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
+                    ORR_TRY(idx->ws_q8err.reserve(2 * sizeof(double) * (size_t)B));
+                    HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s,
+                                                   idx->ws_q8err.as<double>() + B));
+                    epi.i8_rowf = idx->i8_rowf.as<float4>();
+                    epi.i8_qs1 = idx->ws_q8s1.as<float>();
+                }
                 HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
-                                                       idx->ws_fqf.as<float4>(), s));
+                                                       idx->ws_fqf.as<float4>(), s, gemm_i8 ? idx->ws_q8s1.as<float>() : nullptr,
+                                                       gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
-                if (idx->opt_two_stage == 1 && !ts_gemv) ORR_TRY(ensure_shadow(idx));
-                if (ts_i8) {
+                if (gemm_i8) {
+                    ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
+                    HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
+                    Timed t(idx, "screen_i8_fused", 1.0 * (double)n * idx->dim + 1.0 * (double)B * idx->dim);
+                    HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, n, idx->dim, epi, s));
+                } else if (ts_i8) {
                     Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 12.0 * (double)n + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
                                                        idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(), n,

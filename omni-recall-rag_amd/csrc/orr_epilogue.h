@@ -33,7 +33,7 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
                                                int queue_stride)
 {
     const int fr = lane & 31, fh = lane >> 5;
-    float rb[NJ], rr[NJ];
+    float rb[NJ], rr[NJ], ea[NJ], eb[NJ];
     int64_t cols[NJ];
     bool ok[NJ];
 #pragma unroll
@@ -43,6 +43,12 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
         const double2 rc = epi.rowc[ok[j] ? cols[j] : n_rows - 1];
         rb[j] = (float)rc.x;
         rr[j] = ok[j] ? (float)rc.y : -__builtin_huge_valf();              // rows past the end never pass
+        ea[j] = 0.f; eb[j] = 0.f;
+        if (epi.i8_rowf) {                                                 // int8 GEMM: acc is the integer dot
+            const float4 rf = epi.i8_rowf[ok[j] ? cols[j] : n_rows - 1];
+            rb[j] *= rf.x;
+            ea[j] = rf.y; eb[j] = rf.z;
+        }
     }
     const int32_t n_qg = (B + 31) >> 5;
     int parked = 0;
@@ -67,7 +73,7 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
 #pragma unroll
                 for (int p = 0; p < kCountPlanes; ++p) m |= ((w[j][p] >> bit) & 1u) << p;
                 const float a = acc[i][j][e];
-                const float upper = a * (qf.x * rb[j]) + rr[j] + (float)m * qf.z;
+                const float upper = a * (qf.x * rb[j]) + rr[j] + (float)m * qf.z + (ea[j] + qf.w * eb[j]);   // the last term is 0 outside the int8 GEMM
                 // NaN and overflowed sums are never dropped here
                 const bool drop = (upper < qf.y && __builtin_fabsf(a) <= 3.4028234663852886e38f) || qi >= B || !ok[j];
                 if (!drop) {
@@ -99,8 +105,14 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
         const QueryConst qc = epi.qc[qi];
         const double2 rc = epi.rowc[col];
         const uint32_t mm = qc.n_terms > 0 ? kw_matches(epi.kw, qi, (uint32_t)col) : 0u;
-        unsigned long long key = score_key(fused_score_fast((double)pk.a, rc.x, rc.y, mm, qc));
-        if (!(__builtin_fabsf(pk.a) <= 3.4028234663852886e38f)) key = ~0ull;   // kept whatever the floor: re-scored exactly later
+        double dot = (double)pk.a, bound = 0.0;
+        if (epi.i8_rowf) {
+            const float4 rf = epi.i8_rowf[col];
+            dot *= (double)rf.x * (double)epi.i8_qs1[qi];
+            bound = (double)rf.y + (double)epi.qf[qi].w * (double)rf.z;
+        }
+        unsigned long long key = score_key(fused_score_fast(dot, rc.x, rc.y, mm, qc) + bound);
+        if (!(__builtin_fabsf(pk.a) <= 3.4028234663852886e38f) || !(bound <= 1.7976931348623157e308)) key = ~0ull;   // kept whatever the floor: re-scored exactly later
         if (key > epi.tau[qi]) {
             const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
             if (slot < epi.cap) {

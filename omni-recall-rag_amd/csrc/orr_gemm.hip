@@ -433,7 +433,8 @@ hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64
 // qf[b] = {0.7 / sqrt(normA) in fp32 (0 without cosine), floor score - margin, keyword credit per match, 0}
 __global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryConst *__restrict__ qc,
                                                                  const unsigned long long *__restrict__ tau, int32_t B,
-                                                                 float4 *__restrict__ qf)
+                                                                 float4 *__restrict__ qf, const float *__restrict__ i8_qs1,
+                                                                 const double *__restrict__ i8_qerr2)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -452,13 +453,18 @@ __global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryCons
     // count planes saturate at 15: beyond that a row with any match gets the full credit (15 * 0.2/15)
     o.z = c.n_terms > 0 ? __double2float_ru(0.2 / (double)(c.n_terms > 15 ? 15 : c.n_terms)) : 0.f;
     o.w = 0.f;
+    if (i8_qs1) {                                           // int8 screening GEMM: the accumulator is an integer dot
+        o.x *= i8_qs1[b];
+        o.w = c.use_cos ? __double2float_ru(0.7 * 1.000001 * sqrt(i8_qerr2[b]) * c.inv_sqrt_na) : 0.f;
+    }
     qf[b] = o;
 }
 
-hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s)
+hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s,
+                                     const float *i8_qs1, const double *i8_qerr2)
 {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fused_query_consts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, qc, tau, B, qf);
+    hipLaunchKernelGGL(fused_query_consts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, qc, tau, B, qf, i8_qs1, i8_qerr2);
     return hipGetLastError();
 }
 

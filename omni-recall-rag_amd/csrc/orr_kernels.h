@@ -134,6 +134,11 @@ struct FusedEpilogue {
     const float4 *qf;                  // [B] fp32 pre-filter constants (launch_fused_query_consts)
     const uint32_t *count_planes;      // [kCountPlanes][ceil(B/32)][plane_stride] bit-sliced match counts, or null
     int64_t plane_stride;
+    // int8 screening GEMM (K2j) only, else null: per row {se_r, 0.7 (rel_err + 2^-22), rel_hat, 0}; per query s1.
+    // The accumulator then holds the integer dot I: dot^ = s1 se_r I, and qf.x / qf.w carry s1 0.7/sqrt(normA)
+    // and 0.7 |q - q^| / sqrt(normA): score bound = score(dot^) + rowf.y + qf.w rowf.z.
+    const float4 *i8_rowf;
+    const float *i8_qs1;
     uint32_t *cnt;                     // [B]
     SelEntry *buf;                     // [B][cap]
     uint32_t cap;
@@ -144,7 +149,8 @@ hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_sp
 hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
                                   float *S, int64_t s_stride, const FusedEpilogue *epi, int32_t products, hipStream_t s);
 hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s);
-hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s);
+hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s,
+                                     const float *i8_qs1 = nullptr, const double *i8_qerr2 = nullptr);
 // K2c (orr_screen.hip): plain-bf16 screening GEMM (256 x 256 x 64 tiles, LDS-DMA staging) over TILED bf16
 // images of the embeddings (the shard's shadow) and of the batch's queries; S or the fused epilogue as above.
 size_t bf16_tiled_bytes(int64_t n_rows, int32_t D);
@@ -159,10 +165,17 @@ hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_sh
 size_t i8_tiled_bytes(int64_t n_rows, int32_t D);
 hipError_t launch_i8_shadow(const float *E, const double *norm_b, int64_t n_rows, int32_t D, void *tiled, float *scale,
                             float *rel_err, float *rel_hat, hipStream_t s);
-hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s);
+hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s,
+                             double *err2_level1 = nullptr);
 hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double *err2, int32_t B, const void *tiled,
                                  const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, int32_t D,
                                  const FusedEpilogue &epi, bool lower_bound, hipStream_t s);
+// K2j: the screening GEMM on the int8 shadow (v_mfma_i32_32x32x32_i8: twice the bf16 rate, half its bytes).
+// Queries: ONE int8 level (q1 of launch_i8_queries, err2_l1), tiled like the rows; epi must carry i8_rowf / i8_qs1.
+hipError_t launch_i8_rowf(const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, float4 *rowf, hipStream_t s);
+hipError_t launch_i8_tile_queries(const void *q1_linear, int32_t B, int32_t D, void *tiled, hipStream_t s);
+hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D,
+                            const FusedEpilogue &epi, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
 hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
                                   unsigned long long *floor_key, double *L_out, hipStream_t s);

@@ -34,6 +34,7 @@
 #include "orr_epilogue.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace orr {
@@ -55,7 +56,13 @@ __device__ __forceinline__ void glds16(const void *g, unsigned char *l)
     __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, AUX);
 }
 
-template <bool FUSED, int MODE>
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x16v __attribute__((ext_vector_type(16)));
+
+// I8 = true (K2j): the same kernel on the int8 shadow and int8 queries -- an image row's 64 bytes are 64 k,
+// v_mfma_i32_32x32x32_i8 consumes the same 16-byte fragments at twice the rate, the accumulator is the exact
+// integer dot, half as many K-tiles and half the bytes per row.
+template <bool FUSED, int MODE, bool I8>
 __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
                                                              const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
                                                              int32_t D, float *__restrict__ S, int64_t s_stride,
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 
     // tiled operands: K-tile t of this workgroup's query tile / row tile is 16 KiB at base + t * 16 KiB;
     // piece g of a tile (g < 2: A image, g >= 2: B image) is the KiB (g & 1) * 8 + wave of it
-    const int T = D / kScBK;
+    const int T = I8 ? D / 64 : D / kScBK;
     const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * T) * kScImage + wave * 1024 + lane * 16;
     const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * T) * kScImage + wave * 1024 + lane * 16;
     const bool stream_rows = n_mtiles == 1 && (flags & 1);
@@ -89,13 +96,13 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         else glds16<0>(b_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
     };
 
-    f32x16 acc[4][2];
+    typename std::conditional<I8, i32x16v, f32x16>::type acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
     // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
     const int fr = lane & 31, fh = lane >> 5;
@@ -114,7 +121,10 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 
 #define ORR_SB __builtin_amdgcn_sched_barrier(0)
 #define ORR_MM(f, i) \
-    if (MODE != 1 && MODE != 4 && MODE != 5) { \
+    if constexpr (I8) { \
+    acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[0]), acc[i][0], 0, 0, 0); \
+    acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[1]), acc[i][1], 0, 0, 0); \
+    } else if constexpr (MODE != 1 && MODE != 4 && MODE != 5) { \
     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[0], acc[i][0], 0, 0, 0); \
     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[1], acc[i][1], 0, 0, 0); } else { \
     acc[i][0][0] += (float)f.a[i][0] + (float)f.b[0][0]; acc[i][1][0] += (float)f.a[i][1] + (float)f.b[1][0]; } ORR_SB
@@ -167,12 +177,23 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = b0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    if (row < B && col < n_rows && (MODE != 3 || acc[i][j][e] == 1.2345f)) S[(int64_t)row * s_stride + col] = acc[i][j][e];
+                    if (row < B && col < n_rows && (MODE != 3 || acc[i][j][e] == 1.2345f)) S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
                 }
             }
     } else {
         __syncthreads();                                                    // every wave is done with the operand images
-        fused_epilogue<4, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+        if constexpr (I8) {
+            f32x16 accf[4][2];                                              // |I| <= 3072 * 127^2: the conversion costs at most 2^-24
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) accf[i][j][e] = (float)acc[i][j][e];
+            fused_epilogue<4, 2, true>(accf, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+        } else {
+            fused_epilogue<4, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+        }
     }
 }
 
@@ -442,10 +463,11 @@ __global__ __launch_bounds__(256) void i8_shadow_kernel(const float *__restrict_
 
 // Two-level int8 image of up to 8 queries (one workgroup each) and |q - q^|^2.
 __global__ __launch_bounds__(256) void i8_queries_kernel(const float *__restrict__ Qf, int32_t D, int8_t *__restrict__ q1, int8_t *__restrict__ q2,
-                                                         float *__restrict__ s1_out, double *__restrict__ err2_out)
+                                                         float *__restrict__ s1_out, double *__restrict__ err2_out,
+                                                         double *__restrict__ err2_l1_out)
 {
     __shared__ float red_f[4];
-    __shared__ double red_d[4];
+    __shared__ double red_d[4], red_d1[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *q = Qf + (int64_t)b * D;
     float mx = 0.f;
@@ -459,12 +481,13 @@ __global__ __launch_bounds__(256) void i8_queries_kernel(const float *__restrict
     mx = fmaxf(fmaxf(red_f[0], red_f[1]), fmaxf(red_f[2], red_f[3]));
     const bool usable = mx > 0.f && mx <= 3.4028234663852886e38f;
     const float s1 = usable ? mx / 127.f : 0.f, s2 = s1 / 254.f;
-    double e2 = 0.0;
+    double e2 = 0.0, e1 = 0.0;
     for (int k = tid; k < D; k += 256) {
         const float v = q[k];
         int a = usable ? __float2int_rn(v / s1) : 0;
         a = a > 127 ? 127 : (a < -127 ? -127 : a);
         const double r = (double)v - (double)s1 * (double)a;
+        e1 += usable ? r * r : (double)v * (double)v;                           // one level only: q^ = s1 a (int8 GEMM)
         int c2 = (usable && s2 > 0.f) ? __double2int_rn(r / (double)s2) : 0;
         c2 = c2 > 127 ? 127 : (c2 < -127 ? -127 : c2);
         const double dl = r - (double)s1 * ((double)c2 / 254.0);               // q^ = s1 (a + c2 / 254)
@@ -473,13 +496,15 @@ __global__ __launch_bounds__(256) void i8_queries_kernel(const float *__restrict
         q2[(int64_t)b * D + k] = (int8_t)c2;
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) e2 += __shfl_xor(e2, d, 64);
-    if (lane == 0) red_d[wave] = e2;
+    for (int d = 32; d > 0; d >>= 1) { e2 += __shfl_xor(e2, d, 64); e1 += __shfl_xor(e1, d, 64); }
+    if (lane == 0) { red_d[wave] = e2; red_d1[wave] = e1; }
     __syncthreads();
     if (tid == 0) {
         s1_out[b] = s1;
         const double tot = red_d[0] + red_d[1] + red_d[2] + red_d[3];
+        const double tot1 = red_d1[0] + red_d1[1] + red_d1[2] + red_d1[3];
         err2_out[b] = (mx <= 3.4028234663852886e38f) ? tot * 1.000001 : __builtin_huge_val();
+        if (err2_l1_out) err2_l1_out[b] = (mx <= 3.4028234663852886e38f) ? tot1 * 1.000001 : __builtin_huge_val();
     }
 }
 
@@ -530,6 +555,76 @@ hipError_t launch_bf16_tiled(const float *X, int64_t n_rows, int32_t D, void *ou
     return hipGetLastError();
 }
 
+// rowf[r] = {se_r, 0.7 (rel_err + 2^-22) rounded up, rel_hat, 0}: the row constants of the int8 GEMM's epilogue.
+__global__ __launch_bounds__(256) void i8_rowf_kernel(const float *__restrict__ scale, const float *__restrict__ rel_err,
+                                                      const float *__restrict__ rel_hat, int64_t n, float4 *__restrict__ out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        float4 o;
+        o.x = scale[r];
+        o.y = __double2float_ru(0.7 * 1.000002 * ((double)rel_err[r] * 1.0000003 + 2.4e-7) + 1e-9);
+        o.z = __double2float_ru((double)rel_hat[r] * 1.000001);
+        o.w = 0.f;
+        out[r] = o;
+    }
+}
+
+hipError_t launch_i8_rowf(const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, float4 *rowf, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(i8_rowf_kernel, dim3((unsigned)std::min<int64_t>((n_rows + 255) / 256, 4096)), dim3(256), 0, s, scale, rel_err,
+                       rel_hat, n_rows, rowf);
+    return hipGetLastError();
+}
+
+// int8 queries [B][D] -> tiled, swizzled image [query tile][D/64][256][64] (rows past B are zero).
+__global__ __launch_bounds__(256) void i8_tile_queries_kernel(const int8_t *__restrict__ q, int32_t B, int32_t D, int64_t n_chunks,
+                                                              int8_t *__restrict__ out)
+{
+    const int KT = D / 64;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_chunks; o += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(o & 3);
+        const int rr = (int)((o >> 2) & 255);
+        const int64_t tk = o >> 10;
+        const int kt = (int)(tk % KT);
+        const int64_t row = (tk / KT) * kScBM + rr;
+        const int c = slot ^ ((rr >> 2) & 3);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < B) v = *reinterpret_cast<const uint4 *>(q + row * (int64_t)D + kt * 64 + c * 16);
+        *reinterpret_cast<uint4 *>(out + o * 16) = v;
+    }
+}
+
+hipError_t launch_i8_tile_queries(const void *q1_linear, int32_t B, int32_t D, void *tiled, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    if (D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    const int64_t n_chunks = (int64_t)(i8_tiled_bytes(B, D) / 16);
+    hipLaunchKernelGGL(i8_tile_queries_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + 255) / 256, 65536)), dim3(256), 0, s,
+                       static_cast<const int8_t *>(q1_linear), B, D, n_chunks, static_cast<int8_t *>(tiled));
+    return hipGetLastError();
+}
+
+// The int8 screening GEMM over all rows with the fused epilogue (epi.i8_rowf / epi.i8_qs1 set).
+hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D,
+                            const FusedEpilogue &epi, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (D <= 0 || D % 128 != 0 || !epi.i8_rowf || !epi.i8_qs1) return hipErrorInvalidValue;
+    const int64_t n_ntiles = (n_rows + kScBN - 1) / kScBN;
+    const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
+    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kScLds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true>), dim3((unsigned)blocks), dim3(512), kScLds, s,
+                       static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D,
+                       static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi);
+    return hipGetLastError();
+}
+
 size_t i8_tiled_bytes(int64_t n_rows, int32_t D)
 {
     return (size_t)((n_rows + kScBN - 1) / kScBN) * kScBN * (size_t)D;
@@ -549,11 +644,11 @@ hipError_t launch_i8_shadow(const float *E, const double *norm_b, int64_t n_rows
 }
 
 // ws: [q1 B*D][q2 B*D] int8, s1 [B] float, err2 [B] double -- see I8Queries.
-hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s)
+hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s, double *err2_level1)
 {
     if (B <= 0) return hipSuccess;
     int8_t *q1 = static_cast<int8_t *>(q12);
-    hipLaunchKernelGGL(i8_queries_kernel, dim3((unsigned)B), dim3(256), 0, s, Q, D, q1, q1 + (size_t)B * D, s1, err2);
+    hipLaunchKernelGGL(i8_queries_kernel, dim3((unsigned)B), dim3(256), 0, s, Q, D, q1, q1 + (size_t)B * D, s1, err2, err2_level1);
     return hipGetLastError();
 }
 
@@ -629,10 +724,10 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     static const int mode = [] { const char *e = getenv("ORR_SCREEN_MODE"); return e ? atoi(e) : 0; }();
     static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
 #define ORR_LAUNCH(F, M, E) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M>), \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M, false>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<F, M>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
+        hipLaunchKernelGGL((screen_bf16_kernel<F, M, false>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, E); } while (0)
     if (epi) ORR_LAUNCH(true, 0, *epi);
     else if (mode == 1) ORR_LAUNCH(false, 1, none);

@@ -420,7 +420,7 @@ def test_two_stage_batched_pass_matches_oracle():
         rows, scores, counts = idx.search(qs, terms, NOW, topk, candidate_limit=n)
         stats = idx.kernel_stats()
         idx.set_profiling(False)
-        screen = "screen_bf16_fused" if mode == 1 else "gemm_dot_bf16x1_fused"
+        screen = "screen_i8_fused" if mode == 1 else "gemm_dot_bf16x1_fused"      # dim 128: mode 1 screens on the int8 shadow
         assert screen in stats and "rescore_buffer_exact" in stats, stats.keys()
         assert stats["gemm_dot_bf16x3"]["launches"] == 1, stats       # no retry through the unfused pass
         assert all(np.array_equal(x, y) for x, y in zip(plain, (rows, scores, counts)))
