@@ -200,16 +200,16 @@ int orr_index_view(orr_index *parent, orr_index **view);
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
- *   "two_stage"      0/1/2 (default 1): searches over >= 196,608 rows take ONE plain-bf16 product over all
- *                    rows (bound 2^-7 |q||e| on the dot; a stream for 1..8 queries -- over an int8 shadow with a
- *                    per-pair bound for 1..4 when dim % 128 == 0 and it fits, +25 % HBM -- an MFMA GEMM for more),
- *                    keep every (query,row) pair that could reach a lower
- *                    bound of the query's k-th best score, and re-score those in the reference arithmetic on
- *                    the device.  1: the product reads a bf16 shadow copy of the embeddings
- *                    (built at the first such batch, or now if the index is sealed and the option is set
- *                    explicitly; +50 % HBM; silently falls back to 2 when it does not fit).  2: no shadow:
- *                    9+ queries convert the fp32 rows inside the kernel, fewer run the exact kernel.
- *                    0: exact kernel (1..4 queries) / streaming or split-bf16 MFMA pass over all rows. */
+ *   "two_stage"      0/1/2 (default 1): searches over >= 196,608 rows screen ALL rows with ONE low-precision
+ *                    product, keep every (query,row) pair that could reach a lower bound of the query's k-th
+ *                    best score, and re-score those in the reference arithmetic on the device.
+ *                    1: the product reads a shadow copy of the embeddings, built at the first such search (or
+ *                    now if the index is sealed and the option is set explicitly): int8 with one scale per row
+ *                    and a per-pair error bound when dim % 128 == 0 (+25 % HBM; a stream for 1..8 queries, an
+ *                    int8 MFMA GEMM for more), bf16 otherwise (+50 % HBM, bound 2^-7 |q||e|); silently falls
+ *                    back to 2 when the shadow does not fit.  2: no shadow: 9+ queries convert the fp32 rows to
+ *                    bf16 inside the kernel, fewer run the exact kernel.  0: exact kernel (1..4 queries) /
+ *                    streaming or split-bf16 MFMA pass over all rows. */
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
 
 /* Diagnostic: out[B][orr_index_rows] = the screening dots of the two-stage pass (fp32, host or device

@@ -881,7 +881,8 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
         idx->opt_two_stage = (int)value;
         if (value == 1) {
             HIP_TRY(hipSetDevice(idx->device));
-            ORR_TRY(ensure_shadow(idx));
+            ORR_TRY(ensure_i8_shadow(idx));
+            if (!idx->i8_ready) ORR_TRY(ensure_shadow(idx));
         }
         return ORR_OK;
     }
@@ -1082,8 +1083,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (use_cos && !a.force_exact && !a.no_fuse && idx->opt_two_stage == 1 && idx->dim % 64 == 0 && kprime <= orr::kSelWidth &&
         (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
         B <= orr::kMaxGemvScreenQ) {
-        if (B <= orr::kMaxI8ScreenQ) ORR_TRY(ensure_i8_shadow(idx));
-        ts_i8 = B <= orr::kMaxI8ScreenQ && idx->i8_ready;
+        ORR_TRY(ensure_i8_shadow(idx));
+        ts_i8 = idx->i8_ready;                           // 5..8 queries: two launches of the int8 stream
         if (!ts_i8) ORR_TRY(ensure_shadow(idx));
         ts_stream = ts_i8 || idx->shadow_ready;
     }

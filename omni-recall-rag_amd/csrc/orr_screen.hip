@@ -652,30 +652,39 @@ hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, fl
     return hipGetLastError();
 }
 
-// The streaming screen over the int8 shadow.  lower_bound = true: keys are score - bound (prefix floor).
+// The streaming screen over the int8 shadow for up to kMaxGemvScreenQ queries, kMaxI8ScreenQ per launch (two
+// int32 accumulators per query and row).  lower_bound = true: keys are score - bound (prefix floor).
 hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double *err2, int32_t B, const void *tiled,
                                  const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, int32_t D,
                                  const FusedEpilogue &epi, bool lower_bound, hipStream_t s)
 {
     if (B <= 0 || n_rows <= 0) return hipSuccess;
-    if (B > kMaxI8ScreenQ || D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    if (B > kMaxGemvScreenQ || D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
     const int64_t n_units = ((n_rows + kScBN - 1) / kScBN) * 2;
     const int64_t blocks = std::min<int64_t>((n_units + 3) / 4, 512);
-    const size_t lds = 2 * (size_t)B * (size_t)D;
-    if (lds > 65536) return hipErrorInvalidValue;
-    const int8_t *q1 = static_cast<const int8_t *>(q12);
-    I8Queries Qd{q1, q1 + (size_t)B * D, s1, err2};
+    const int8_t *q1 = static_cast<const int8_t *>(q12), *q2 = q1 + (size_t)B * D;
     I8Rows Rd{static_cast<const int8_t *>(tiled), scale, rel_err, rel_hat};
-#define ORR_I8(NQ) do { if (lower_bound) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, epi); \
-                        else hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, false>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, epi); } while (0)
-    switch (B) {
-    case 1: ORR_I8(1); break;
-    case 2: ORR_I8(2); break;
-    case 3: ORR_I8(3); break;
-    default: ORR_I8(4); break;
-    }
+    for (int32_t b0 = 0; b0 < B; b0 += kMaxI8ScreenQ) {
+        const int32_t nb = std::min<int32_t>(kMaxI8ScreenQ, B - b0);
+        const size_t lds = 2 * (size_t)nb * (size_t)D;
+        if (lds > 65536) return hipErrorInvalidValue;
+        I8Queries Qd{q1 + (size_t)b0 * D, q2 + (size_t)b0 * D, s1 + b0, err2 + b0};
+        FusedEpilogue e2 = epi;                              // everything the kernel indexes by query, shifted to b0
+        e2.qc += b0; e2.tau += b0; e2.cnt += b0; e2.buf += (size_t)b0 * epi.cap;
+        if (e2.kw.q_term_off) e2.kw.q_term_off += b0;
+#define ORR_I8(NQ) do { if (lower_bound) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
+                        else hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, false>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); } while (0)
+        switch (nb) {
+        case 1: ORR_I8(1); break;
+        case 2: ORR_I8(2); break;
+        case 3: ORR_I8(3); break;
+        default: ORR_I8(4); break;
+        }
 #undef ORR_I8
-    return hipGetLastError();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // The screening pass for B <= kMaxGemvScreenQ queries: q_hi is the linear [B][D] bf16 image (hi halves of

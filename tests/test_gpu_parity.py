@@ -436,7 +436,7 @@ def test_two_stage_batched_pass_matches_oracle():
         idx.set_profiling(True)
         rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
         st = idx.kernel_stats()
-        assert ("screen_gemv_i8" if nb <= 4 else "screen_gemv_bf16") in st, sorted(st)       # dim 128: the int8 shadow applies
+        assert "screen_gemv_i8" in st, sorted(st)       # dim 128: the int8 shadow applies (two launches beyond 4 queries)
         idx.set_profiling(False)
         for b in range(nb):
             orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
