@@ -492,6 +492,61 @@ def test_two_stage_pass_with_rows_that_are_hot_for_every_query():
     idx.close()
 
 
+def test_int8_shadow_with_rows_and_queries_that_quantise_badly():
+    """The int8 screens (stream for 1..8 queries, MFMA GEMM beyond) rely on a per-pair bound computed from the
+    actual quantisation errors.  Rows and queries chosen to make one scale per vector a poor fit -- a single
+    huge coordinate, tiny and huge magnitudes, zero rows, a constant vector -- must still give the reference's
+    answer bit for bit (such rows simply survive the screen)."""
+    P = pkg()
+    rng = np.random.default_rng(80)
+    n, dim = 200_000, 128
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    emb[0:100] *= np.float32(1e-6)
+    emb[100:200, 7] = np.float32(1000.0)                                  # one coordinate dominates the scale
+    emb[200:300] = 0.0
+    emb[300:400] *= np.float32(1e30)
+    emb[400:500] = np.float32(0.37)                                       # constant rows
+    emb[500:600, ::2] = 0.0
+    perm = rng.permutation(n)
+    emb = emb[perm]                                                       # spread the odd rows over the corpus
+    where = np.empty(n, dtype=np.int64)
+    where[perm] = np.arange(n)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta"])
+    contents = [" ".join(w).encode() for w in words[rng.integers(0, len(words), (n, 3))]]
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], contents[r0:r0 + 50_000])
+    idx.seal()
+    B = 40
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[0] = 0.0; qs[0, 7] = 100.0                                         # spiky query: likes the spiky rows
+    qs[1] *= np.float32(1e-8)
+    qs[2] = emb[where[150]]
+    qs[3] = emb[where[350]]                                               # huge magnitude
+    qs[4] = 0.37
+    qs[5] = emb[where[50]]                                                # tiny magnitude
+    qs[6, 1::2] = 0.0
+    texts = ["alpha", "", "beta gamma", "delta", "", "alpha beta", ""] + [""] * (B - 7)
+    terms = [P.text.query_terms(t) if t else [] for t in texts]
+    corpus = orc.OracleCorpus(emb, created, contents)
+    idx.set_profiling(True)
+    r4, s4, c4 = idx.search(qs[:4], terms[:4], NOW, 10, candidate_limit=n)            # int8 stream
+    r7, s7, c7 = idx.search(qs[:7], terms[:7], NOW, 10, candidate_limit=n)            # two launches of it
+    rB, sB, cB = idx.search(qs, terms, NOW, 10, candidate_limit=n)                    # int8 GEMM
+    stats = idx.kernel_stats()
+    idx.set_profiling(False)
+    assert "screen_gemv_i8" in stats and "screen_i8_fused" in stats, sorted(stats)
+    for b in range(8):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+        for name, (rr, ss, cc) in (("stream", (r4, s4, c4)), ("stream2", (r7, s7, c7)), ("gemm", (rB, sB, cB))):
+            if b >= len(cc):
+                continue
+            assert list(rr[b, :cc[b]]) == list(orow), (name, b)
+            assert np.array_equal(ss[b, :cc[b]], osc), (name, b)
+    idx.close()
+
+
 def test_empty_and_degenerate_inputs():
     """Empty corpus, rows with empty content, queries without terms or vectors, API misuse."""
     P = pkg()
