@@ -452,6 +452,13 @@ def test_two_stage_batched_pass_matches_oracle():
     idx.set_option("two_stage", 0)
     plain = idx.search(qs, terms, NOW, 10, candidate_limit=n)
     assert np.array_equal(mrows, plain[0]) and np.array_equal(mscores, plain[1])
+    # ... and so does a small sharded batch (the multi-GPU bench sends one query per rank): streaming form
+    idx.set_option("two_stage", 1)
+    for nb in (1, 3, 8):
+        recs = idx.search_shard(qs[:nb], terms[:nb], NOW, kprime, candidate_limit=n)
+        mrows, mscores, mcounts, unc = P.merge_candidates(recs[None], dim, qs[:nb], terms[:nb], NOW, 10)
+        assert unc == 0
+        assert np.array_equal(mrows, plain[0][:nb]) and np.array_equal(mscores, plain[1][:nb]), nb
     idx.close()
 
 
