@@ -515,16 +515,45 @@ hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float
 }
 
 // Reference-order fp64 dots (RecallSearchService.cs:77-82) of one query against up to 64 gathered rows,
-// one row per lane: the rows' 64-column pieces go through a wave-private XOR-swizzled LDS tile (coalesced
-// 256-byte reads per row piece, conflict-free ds_read_b128 per lane), the next piece already requested
-// while the current one is summed.  (Two pieces ahead needs 170 VGPRs and measured slower at every batch
-// size: with many waves the occupancy matters more, with few the serial fp64 chain sets the pace.)
+// one row per lane.  The rows are scattered, so there is nothing to coalesce: every lane reads its own row
+// straight into registers, 64 columns (sixteen 16-byte loads, eight per 128-byte line) at a time, the next
+// 64 already requested while the current ones go through the serial fp64 chain.  (The first version staged
+// the pieces through a wave-private LDS tile as the contiguous-row kernel does: 100 us per wave at D = 3072
+// against the chain's own ~15 us; ORR_RESCORE_LDS=1 keeps it for comparison.)
 // rows[] (LDS, 64 entries, -1 = none) must be visible to the wave.  D % 64 == 0.
+template <bool VIA_LDS>
 __device__ __forceinline__ double exact_dot_of_gathered_rows(const float *__restrict__ E, int32_t D, const float *__restrict__ q,
                                                              const int64_t *rows, float *tile, int lane)
 {
-    const int ld_row = lane >> 4, ld_ch = lane & 15;
     double acc = 0.0;
+    if (!VIA_LDS) {
+        const int64_t row = rows[lane];
+        const float *src = E + (row >= 0 ? row : 0) * (int64_t)D;              // lanes without a row read row 0 and are ignored
+        float4 cur[16], nxt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur[j] = *reinterpret_cast<const float4 *>(src + j * 4);
+        for (int c0 = 0; c0 < D; c0 += 64) {
+            const int cn = c0 + 64 < D ? c0 + 64 : c0;                         // clamped, never branched around
+#pragma unroll
+            for (int j = 0; j < 16; ++j) nxt[j] = *reinterpret_cast<const float4 *>(src + cn + j * 4);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float *qp = q + c0 + j * 4;
+                float p0 = qp[0] * cur[j].x;
+                acc += (double)p0;
+                float p1 = qp[1] * cur[j].y;
+                acc += (double)p1;
+                float p2 = qp[2] * cur[j].z;
+                acc += (double)p2;
+                float p3 = qp[3] * cur[j].w;
+                acc += (double)p3;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
+        }
+        return acc;
+    }
+    const int ld_row = lane >> 4, ld_ch = lane & 15;
     float4 stage[16];
     auto load_stage = [&](int c0) {
 #pragma unroll
@@ -600,6 +629,7 @@ hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, do
 // Two-stage pass, second stage: every buffered (query,row) pair gets its score again from the
 // reference-order fp64 dot (same wave-private swizzled tile walk as K6) and the exact fused
 // formula; the entry's key is overwritten with it.  One wave per 64 buffer entries of a query.
+template <bool VIA_LDS>
 __global__ __launch_bounds__(64) void rescore_buffer_exact_kernel(const float *__restrict__ E, int32_t D,
                                                                   const float *__restrict__ Q,
                                                                   const double *__restrict__ norm_b,
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(64) void rescore_buffer_exact_kernel(const float *_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double acc = exact_dot_of_gathered_rows(E, D, Q + (int64_t)b * D, rows, tile, lane);
+    const double acc = exact_dot_of_gathered_rows<VIA_LDS>(E, D, Q + (int64_t)b * D, rows, tile, lane);
     if (live) {
         const QueryConst qc = qcs[b];
         const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
@@ -674,8 +704,13 @@ hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q
 {
     if (B <= 0) return hipSuccess;
     if (D % 64 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rescore_buffer_exact_kernel, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
-                       now_ticks, cnt, cap, buf, buf_dot);
+    static const bool via_lds = [] { const char *e = getenv("ORR_RESCORE_LDS"); return e && atoi(e) != 0; }();
+    if (via_lds)
+        hipLaunchKernelGGL(rescore_buffer_exact_kernel<true>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
+                           now_ticks, cnt, cap, buf, buf_dot);
+    else
+        hipLaunchKernelGGL(rescore_buffer_exact_kernel<false>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
+                           now_ticks, cnt, cap, buf, buf_dot);
     return hipGetLastError();
 }
 
@@ -1006,6 +1041,7 @@ hipError_t launch_gemv_mfma(const float *Q, int32_t B, const float *E, int64_t n
 // the records' candidate positions.  Writes the reference-order fp64 dot into the record
 // and marks it ORR_CAND_DOT_EXACT.
 // ---------------------------------------------------------------------------
+template <bool VIA_LDS>
 __global__ __launch_bounds__(64) void rescore_exact_kernel(const float *__restrict__ E, int32_t D,
                                                            const float *__restrict__ Q, int32_t B, int32_t kprime,
                                                            int64_t row_base, orr_candidate *__restrict__ recs)
@@ -1022,7 +1058,7 @@ __global__ __launch_bounds__(64) void rescore_exact_kernel(const float *__restri
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double acc = exact_dot_of_gathered_rows(E, D, Q + (int64_t)b * D, rows, tile, lane);
+    const double acc = exact_dot_of_gathered_rows<VIA_LDS>(E, D, Q + (int64_t)b * D, rows, tile, lane);
     if (my_row >= 0) {
         mine[lane].dot = acc;
         mine[lane].flags |= ORR_CAND_DOT_EXACT;
@@ -1055,7 +1091,9 @@ hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32
 {
     if (B <= 0 || D <= 0) return hipSuccess;
     if (kprime <= 64 && D % 64 == 0 && (reinterpret_cast<uintptr_t>(E) & 15) == 0) {
-        hipLaunchKernelGGL(rescore_exact_kernel, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
+        static const bool via_lds = [] { const char *e = getenv("ORR_RESCORE_LDS"); return e && atoi(e) != 0; }();
+        if (via_lds) hipLaunchKernelGGL(rescore_exact_kernel<true>, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
+        else hipLaunchKernelGGL(rescore_exact_kernel<false>, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
     } else {
         const int64_t threads = (int64_t)B * kprime;
         hipLaunchKernelGGL(rescore_exact_generic, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, D, Q, B, kprime,
