@@ -165,7 +165,7 @@ struct orr_index {
     bool i8_ready = false, i8_failed = false;
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
@@ -454,7 +454,7 @@ void orr_index_destroy(orr_index *idx)
         for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat, &idx->i8_rowf}) { b->p = nullptr; b->cap = 0; }
     }
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
-                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
+                      &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
@@ -1407,12 +1407,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                     // the sample goes through the stream too: floor keys of 0 keep every sampled row, their
                     // approximate keys are sorted in lists of 64 and the k-th best one per query is the floor's base
                     const uint32_t cap_p = (uint32_t)dotf_rows;                 // a multiple of 4096
-                    const int32_t lists_p = (int32_t)(cap_p / orr::kSelWidth);
                     ORR_TRY(idx->ws_pbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
-                    ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
-                    HIP_TRY(hipMemsetAsync(idx->ws_tskey.p, 0, sizeof(unsigned long long) * (size_t)B, s));
+                    if (idx->ws_zero.cap < sizeof(unsigned long long) * (size_t)B) {   // floor keys of 0, never written again
+                        ORR_TRY(idx->ws_zero.reserve(sizeof(unsigned long long) * (size_t)std::max<int32_t>(B, 64)));
+                        HIP_TRY(hipMemsetAsync(idx->ws_zero.p, 0, idx->ws_zero.cap, s));
+                    }
                     orr::FusedEpilogue pre = epi;
-                    pre.tau = idx->ws_tskey.as<unsigned long long>();
+                    pre.tau = idx->ws_zero.as<unsigned long long>();
                     pre.buf = idx->ws_pbuf.as<orr::SelEntry>();
                     pre.cap = cap_p;
                     {
@@ -1424,8 +1425,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                         else
                             HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, std::min<int64_t>(dotf_rows, n), idx->dim, pre, s));
                     }
-                    {
+                    {   // lists of 64 sorted in parallel, then the k-th best key per query
                         Timed t(idx, "select_floor", 0.0);
+                        const int32_t lists_p = (int32_t)(cap_p / orr::kSelWidth);
+                        ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
                         HIP_TRY(orr::launch_buffer_to_lists(pre.buf, pre.cnt, cap_p, B, 0, lists_p, idx->ws_psel.as<orr::SelEntry>(), s));
                         HIP_TRY(orr::launch_select_final_sample(idx->ws_psel.as<orr::SelEntry>(), lists_p, lists_p, B, kth, d_tau, s));
                     }
@@ -1453,9 +1456,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                     epi.i8_rowf = idx->i8_rowf.as<float4>();
                     epi.i8_qs1 = idx->ws_q8s1.as<float>();
                 }
-                HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
-                                                       idx->ws_fqf.as<float4>(), s, gemm_i8 ? idx->ws_q8s1.as<float>() : nullptr,
-                                                       gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr));
+                if (!ts_gemv)                    // the streaming kernels score in fp64 directly, no fp32 pre-filter constants
+                    HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
+                                                           idx->ws_fqf.as<float4>(), s, gemm_i8 ? idx->ws_q8s1.as<float>() : nullptr,
+                                                           gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (gemm_i8) {
                     ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
