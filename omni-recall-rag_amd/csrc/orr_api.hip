@@ -1342,19 +1342,21 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         }
     }
     HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
+    // per-row selection constants do not depend on the keyword side: enqueued before the main stream waits for it
+    const double2 *d_rowc_early = nullptr;
+    if (batched_score && kprime <= orr::kSelWidth) {
+        ORR_TRY(idx->ws_rowc.reserve(sizeof(double2) * (size_t)n));
+        Timed t(idx, "row_consts", 32.0 * (double)n);
+        HIP_TRY(orr::launch_row_consts(idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->ws_rowc.as<double2>(), s));
+        d_rowc_early = idx->ws_rowc.as<double2>();
+    }
     if (n_terms_total > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_kw_done, 0));
 
     // ---- K4/K5 fused score + selection
     if (kprime <= orr::kSelWidth) {
         const int64_t n_seg = (n + orr::kSelSegRows - 1) / orr::kSelSegRows;
         ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)n_seg * orr::kSelWidth));
-        const double2 *d_rowc = nullptr;
-        if (batched_score) {
-            ORR_TRY(idx->ws_rowc.reserve(sizeof(double2) * (size_t)n));
-            Timed t(idx, "row_consts", 32.0 * (double)n);
-            HIP_TRY(orr::launch_row_consts(idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->ws_rowc.as<double2>(), s));
-            d_rowc = idx->ws_rowc.as<double2>();
-        }
+        const double2 *d_rowc = d_rowc_early;
         const int32_t n_seg32 = (int32_t)n_seg;
         unsigned long long *d_tau = nullptr;
         if (fused_sample_seg > 0) {
