@@ -119,3 +119,22 @@ def test_batched_passes_equal_the_exact_pass_at_1m(big):
         r4, s4, _ = idx.search(q[b0:b0 + 4], terms[b0:b0 + 4], syn.NOW_TICKS, 10, candidate_limit=m)
         assert np.array_equal(r[b0:b0 + 4], r4) and np.array_equal(s[b0:b0 + 4], s4)
     assert (r < m).all()
+
+
+def test_large_topk_through_the_two_stage_pass_at_1m(big):
+    """topK = 50 (k' = 64, the widest the selection kernels carry) and topK = 60 (generic sort path) agree with
+    the exact kernel for a single query and for a batch."""
+    P, syn, idx, n, dim = big
+    B = 12
+    q = syn.query_vectors(5000, B, dim, n, "cuda:0")
+    terms = [P.text.query_terms(t) for t in syn.query_texts(5000, B, n)]
+    for topk in (50, 60):
+        idx.set_option("two_stage", 0)
+        want = [idx.search(q[b:b + 1], terms[b:b + 1], syn.NOW_TICKS, topk, candidate_limit=n) for b in range(3)]
+        idx.set_option("two_stage", 1)
+        got1 = [idx.search(q[b:b + 1], terms[b:b + 1], syn.NOW_TICKS, topk, candidate_limit=n) for b in range(3)]
+        gotB = idx.search(q, terms, syn.NOW_TICKS, topk, candidate_limit=n)
+        for b in range(3):
+            assert want[b][2][0] == topk
+            assert all(np.array_equal(x, y) for x, y in zip(want[b], got1[b])), (topk, b)
+            assert np.array_equal(gotB[0][b], want[b][0][0]) and np.array_equal(gotB[1][b], want[b][1][0]), (topk, b)
