@@ -141,7 +141,8 @@ def main():
     for s in range(n_steps_total):
         b0 = (s * world + rank) * B_local
         q_steps.append(syn.query_vectors(b0, B_local, dim, n_total, dev))
-        term_steps.append([[] if args.no_terms else P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])
+        # tokenised and packed into the ABI's term arrays up front, like the query vectors (host-side input preparation)
+        term_steps.append(P.PackedTerms(P.pack_terms([[] if args.no_terms else P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])))
     torch.cuda.synchronize()
 
     n_lanes = max(1, args.inflight) if front is None else 1

@@ -53,16 +53,15 @@ def pack_terms(queries_terms) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """[[term bytes]] per query -> (terms_utf8, term_off, query_term_off) of the ABI."""
     if isinstance(queries_terms, PackedTerms):
         return queries_terms.arrays
-    pool = bytearray()
-    term_off = [0]
-    qoff = [0]
-    for terms in queries_terms:
-        for t in terms:
-            pool += bytes(t)
-            term_off.append(len(pool))
-        qoff.append(len(term_off) - 1)
-    pool_arr = np.frombuffer(bytes(pool) + b"\0", dtype=np.uint8).copy()
-    return pool_arr, np.asarray(term_off, dtype=np.uint32), np.asarray(qoff, dtype=np.uint32)
+    flat = [bytes(t) for terms in queries_terms for t in terms]
+    pool_arr = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8).copy()
+    term_off = np.zeros(len(flat) + 1, dtype=np.uint32)
+    if flat:
+        np.cumsum(np.fromiter(map(len, flat), dtype=np.int64, count=len(flat)), out=term_off[1:])
+    qoff = np.zeros(len(queries_terms) + 1, dtype=np.uint32)
+    if len(queries_terms):
+        np.cumsum(np.fromiter(map(len, queries_terms), dtype=np.int64, count=len(queries_terms)), out=qoff[1:])
+    return pool_arr, term_off, qoff
 
 
 def pack_contents(contents: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
