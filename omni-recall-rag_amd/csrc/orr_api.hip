@@ -1077,8 +1077,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     // Batched candidate pass on the matrix cores (K2) + exact re-score (K6) from this batch size
     // up; below it the HBM-bound exact kernel is as fast and needs no second pass.
     static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
-    // 1..8 queries over a large shard with the bf16 shadow in place: the streaming form of the two-stage pass
-    // (f32 streaming MFMA kernel over a sampled prefix -> floor, K2g over the shadow -> survivors, exact re-score)
+    // 1..8 queries over a large shard with a shadow in place: the streaming form of the two-stage pass
+    // (stream over a sampled prefix -> floor, stream over all rows -> survivors, exact re-score)
     bool ts_stream = false, ts_i8 = false;
     if (use_cos && !a.force_exact && !a.no_fuse && idx->opt_two_stage == 1 && idx->dim % 64 == 0 && kprime <= orr::kSelWidth &&
         (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
@@ -1159,8 +1159,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                  std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
         static const int ts_min_batch = [] { const char *e = getenv("ORR_TS_MIN_BATCH"); return e ? atoi(e) : 5; }();
         if (ts_stream) {
-            // 1..8 queries: HBM-bound, so no GEMM tile: the f32 streaming MFMA kernel over the prefix gives the
-            // floor and the shadow is streamed by the dot2 kernel (K2g) for all queries at once
+            // 1..8 queries: HBM-bound, so no GEMM tile: the streaming screen (K2i on the int8 shadow, else K2g on the
+            // bf16 one) runs over the sample for the floor and then over all rows
             ts_gemv = true;
             two_stage = true;
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
