@@ -137,7 +137,8 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     // One LDS-DMA piece per pair of MFMAs in the first half of the tile.  (Measured alternatives, 1M x 3072
     // rows x 256 queries: all four pieces right after the barrier, or the SIMD's two waves taking the
     // request half and the multiply half of the period in opposite order: both 5-8 % slower;
-    // s_setprio(1) around every MFMA pair: no gain.)
+    // s_setprio(1) around every MFMA pair: no gain; a fourth tile in flight instead of the early fragment
+    // reads of tile t+1: 12 % slower; not requesting query pieces past the batch: no change.)
 #define ORR_TILE(CUR0, CUR1, NXT0, NXT1, t) \
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (kScNS - 3)) : "memory"); \
     issue_piece((t) + kScNS - 1, 0); ORR_SB; \
