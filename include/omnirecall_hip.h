@@ -83,6 +83,7 @@ typedef struct orr_candidate {
 #define ORR_CAND_DOT_EXACT 2   /* `dot` is already the reference-order fp64 sum */
 #define ORR_CAND_OVERFLOW  4   /* trailer only: the shard's candidate buffer overflowed; repeat unfused */
 #define ORR_CAND_TWO_STAGE 8   /* trailer only: norm_b holds L; every row not offered has an exact score < L */
+#define ORR_CAND_DEAD      16  /* the row was deleted (orr_index_delete_rows): the host finish drops the record */
 
 /* Per-kernel timing collected with HIP events on the index's own stream. */
 typedef struct orr_kernel_stat {
@@ -196,8 +197,27 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out);
  * parent; it cannot be appended to, sealed again or saved. */
 int orr_index_view(orr_index *parent, orr_index **view);
 
+/* ---- deletes without a reseal -------------------------------------------------
+ * Replaces InMemoryIngestionStore.DeleteDocumentAsync (InMemoryIngestionStore.cs:50-55) and the
+ * "replace the chunk list" half of UpsertChunksAsync (:17-25) on a SEALED shard: the rows with the given
+ * ids (the ids of orr_index_append) stop taking part in every later search, exactly as if the shard had
+ * been rebuilt without them -- they are not ranked, and they do not count towards candidate_limit.  The
+ * rows keep their positions (order_key of the others is unchanged, so is every row id), nothing is moved
+ * in HBM: the cost is one small upload.  On the device a deleted row's norm and timestamp are overwritten
+ * (its score drops to the keyword part, <= 0.2), its records are flagged ORR_CAND_DEAD and the host finish
+ * (orr_search_batch, orr_merge_candidates) drops them; the certificate logic is unchanged, so results stay
+ * exact.  Unknown and already deleted ids are skipped; *out_deleted (may be NULL) = rows newly deleted.
+ * Exclusive like append/seal: no search may be in flight on the index or its views.  Views see the
+ * deletes of their parent.  ORR_ESTATE once more than a quarter of the shard is deleted: rebuild it.
+ * orr_index_live_rows = rows - deleted rows.  A shard behind others in the global order is told how many
+ * deleted rows lie in front of it with the "dead_rows_before" option, so that candidate_limit keeps
+ * counting live rows only.  orr_index_save / orr_index_load keep the deleted set. */
+int     orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int64_t *out_deleted);
+int64_t orr_index_live_rows(const orr_index *idx);
+
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
+ *   "dead_rows_before"  deleted rows in the shards in front of this one (default 0), see above.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
  *   "two_stage"      0/1/2 (default 1): searches over >= 196,608 rows screen ALL rows with ONE low-precision

@@ -85,10 +85,13 @@ void          orrh_service_destroy(orrh_service *svc);
 /* Index maintenance: documents uploaded after the last build whose chunks are
  * all strictly newer than everything indexed become a small DELTA shard placed in front of the
  * existing ones (candidate order is CreatedAt-descending); searches then run per shard and are
- * merged exactly like a multi-GPU search (orr_search_shard + orr_merge_candidates).  Deletes,
- * replaced chunk lists, older timestamps, a different embedding dimension or more than 8 shards
- * trigger a full rebuild.  Counters for tests/metrics: */
+ * merged exactly like a multi-GPU search (orr_search_shard + orr_merge_candidates).  A deleted document
+ * and a document whose chunk list was replaced (InMemoryIngestionStore.cs:17-25, 50-55) lose their rows in
+ * place (orr_index_delete_rows: no reseal, row ids of the others unchanged); a replaced list then counts
+ * as new.  Older timestamps, a different embedding dimension, more than 8 shards or more than a quarter of
+ * a shard deleted trigger a full rebuild.  Counters for tests/metrics: */
 void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebuilds, int64_t *delta_builds);
+int64_t orrh_service_tombstoned_rows(orrh_service *svc);    /* rows dropped in place so far */
 /* SearchAsync(query, topK) with the query embedding supplied by the caller (the
  * IEmbeddingClient result; qdim 0 = empty vector) and a frozen clock.  *out_json is
  * malloc'd; release it with orrh_free.  A blank query is ORR_EINVAL "Query is required." */

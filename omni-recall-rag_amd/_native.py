@@ -22,7 +22,7 @@ class OrrError(RuntimeError):
 
 
 ORR_OK, ORR_EINVAL, ORR_ENOMEM, ORR_EDEVICE, ORR_ECOMM, ORR_EDIM, ORR_ESTATE = 0, -1, -2, -3, -4, -5, -6
-ORR_CAND_TRAILER, ORR_CAND_DOT_EXACT = 1, 2
+ORR_CAND_TRAILER, ORR_CAND_DOT_EXACT, ORR_CAND_DEAD = 1, 2, 16
 
 
 class OrrConfig(C.Structure):
@@ -82,6 +82,10 @@ hip.orr_index_load.restype = C.c_int
 hip.orr_index_load.argtypes = [C.POINTER(OrrConfig), C.c_char_p, C.POINTER(_vp)]
 hip.orr_index_set_option.restype = C.c_int
 hip.orr_index_set_option.argtypes = [_vp, C.c_char_p, _i64]
+hip.orr_index_delete_rows.restype = C.c_int
+hip.orr_index_delete_rows.argtypes = [_vp, _i64, _vp, _vp]
+hip.orr_index_live_rows.restype = _i64
+hip.orr_index_live_rows.argtypes = [_vp]
 hip.orr_index_view.restype = C.c_int
 hip.orr_index_view.argtypes = [_vp, C.POINTER(_vp)]
 hip.orr_index_screen_dots.restype = C.c_int
@@ -122,6 +126,8 @@ host.orrh_service_create.restype = _vp
 host.orrh_service_create.argtypes = [_vp, _i32, _i64]
 host.orrh_service_stats.restype = None
 host.orrh_service_stats.argtypes = [_vp, _vp, _vp, _vp]
+host.orrh_service_tombstoned_rows.restype = _i64
+host.orrh_service_tombstoned_rows.argtypes = [_vp]
 host.orrh_service_destroy.restype = None
 host.orrh_service_destroy.argtypes = [_vp]
 host.orrh_service_search_json.restype = C.c_int
@@ -150,12 +156,13 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
     "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
     "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_view",
+    "orr_index_delete_rows", "orr_index_live_rows",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_service_create", "orrh_service_destroy",
-                         "orrh_service_search_json", "orrh_service_stats", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
+                         "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
                          "orrh_batcher_search", "orrh_batcher_stats"]
 
 

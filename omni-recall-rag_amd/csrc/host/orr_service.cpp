@@ -49,7 +49,9 @@ struct Shard {                       // one sealed orr_index and the chunks behi
     std::vector<Chunk> chunks;       // row id = id_base + position in this vector
     int64_t id_base = 0;
     int64_t min_created = 0, max_created = 0;
-    std::map<std::string, uint64_t> doc_stamps;
+    std::map<std::string, uint64_t> doc_stamps;      // documents with live rows here -> version of their chunk list
+    std::vector<char> dead;          // rows deleted in place (orr_index_delete_rows), by position in `chunks`
+    int64_t n_dead = 0;
 };
 
 struct orrh_service {
@@ -61,7 +63,7 @@ struct orrh_service {
     int32_t dim = 0;
     uint64_t built_version = ~0ull;
     int64_t next_id = 0;
-    int64_t full_rebuilds = 0, delta_builds = 0;
+    int64_t full_rebuilds = 0, delta_builds = 0, tombstoned_rows = 0;
 };
 
 namespace {
@@ -201,10 +203,12 @@ int32_t majority_dim(const std::vector<Chunk> &chunks)
 
 void assign_row_bases(orrh_service *svc)
 {
-    int64_t base = 0;
+    int64_t base = 0, dead = 0;
     for (auto &sh : svc->shards) {                    // newest shard first
         orr_index_set_row_base(sh.index, base);
+        orr_index_set_option(sh.index, "dead_rows_before", dead);      // candidate_limit counts live rows
         base += (int64_t)sh.chunks.size();
+        dead += sh.n_dead;
     }
 }
 
@@ -216,13 +220,36 @@ int ensure_index(orrh_service *svc)
     orrh_store *st = svc->store;
     if (!svc->shards.empty() && svc->built_version == st->chunks_version) return ORR_OK;
 
-    // what is indexed vs what the store holds now
+    // what is indexed vs what the store holds now.  Documents that were deleted, or whose chunk list was
+    // replaced (InMemoryIngestionStore.cs:17-25, 50-55), lose their rows in place: orr_index_delete_rows,
+    // no reseal; a replaced list then counts as new below.
     std::map<std::string, uint64_t> indexed;
-    for (const auto &sh : svc->shards) for (const auto &kv : sh.doc_stamps) indexed[kv.first] = kv.second;
     bool changed = false;
-    for (const auto &kv : indexed) {
-        auto it = st->chunk_stamp.find(kv.first);
-        if (it == st->chunk_stamp.end() || it->second != kv.second) { changed = true; break; }
+    for (auto &sh : svc->shards) {
+        std::vector<std::string> stale;
+        for (const auto &kv : sh.doc_stamps) {
+            auto it = st->chunk_stamp.find(kv.first);
+            if (it == st->chunk_stamp.end() || it->second != kv.second) stale.push_back(kv.first);
+        }
+        if (!stale.empty() && !changed) {
+            if (sh.dead.empty()) sh.dead.assign(sh.chunks.size(), 0);
+            std::vector<int64_t> ids;
+            for (size_t p = 0; p < sh.chunks.size(); ++p)
+                if (!sh.dead[p] && std::binary_search(stale.begin(), stale.end(), sh.chunks[p].document_id)) {
+                    ids.push_back(sh.id_base + (int64_t)p);
+                    sh.dead[p] = 1;
+                }
+            int64_t done = 0;
+            const int r = orr_index_delete_rows(sh.index, (int64_t)ids.size(), ids.data(), &done);
+            if (r == ORR_ESTATE) changed = true;              // too much of the shard is gone: rebuild below
+            else if (r != ORR_OK) return fail(r, orr_last_error());
+            else {
+                sh.n_dead += done;
+                svc->tombstoned_rows += done;
+                for (const auto &d : stale) sh.doc_stamps.erase(d);
+            }
+        }
+        for (const auto &kv : sh.doc_stamps) indexed[kv.first] = kv.second;
     }
     std::vector<Chunk> added;
     std::map<std::string, uint64_t> added_stamps;
@@ -399,6 +426,13 @@ void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebu
     if (n_shards) *n_shards = (int32_t)svc->shards.size();
     if (full_rebuilds) *full_rebuilds = svc->full_rebuilds;
     if (delta_builds) *delta_builds = svc->delta_builds;
+}
+
+int64_t orrh_service_tombstoned_rows(orrh_service *svc)
+{
+    if (!svc) return 0;
+    std::lock_guard<std::mutex> l(svc->mu);
+    return svc->tombstoned_rows;
 }
 
 void orrh_free(void *p) { free(p); }

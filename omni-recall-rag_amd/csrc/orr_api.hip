@@ -163,6 +163,12 @@ struct orr_index {
     bool shadow_ready = false, shadow_failed = false;
     DevBuf emb_i8, i8_scale, i8_rel_err, i8_rel_hat, i8_rowf;   // int8 shadow: streaming screen of 1..4 queries (K2i), screening GEMM (K2j)
     bool i8_ready = false, i8_failed = false;
+    // deleted rows (orr_index_delete_rows): ascending positions, mirrored on the device for the record flags
+    std::vector<int64_t> dead;
+    DevBuf d_dead;
+    int64_t dead_before = 0;           // deleted rows in the shards in front of this one ("dead_rows_before")
+    const orr_index *parent = nullptr; // views: the deleted set lives in the owning index
+    std::vector<std::pair<int64_t, int64_t>> id_index;   // (row id, position) ascending, built at the first delete
 
     // search workspace
     DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero;
@@ -453,6 +459,7 @@ void orr_index_destroy(orr_index *idx)
         idx->emb_shadow.p = nullptr; idx->emb_shadow.cap = 0;
         for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat, &idx->i8_rowf}) { b->p = nullptr; b->cap = 0; }
     }
+    idx->d_dead.release();
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
@@ -715,6 +722,7 @@ int orr_index_save(orr_index *idx, const char *path)
     memcpy(h.magic, "ORRSHD1", 8);
     h.version = 1; h.dim = (uint32_t)idx->dim; h.n_rows = idx->n_rows; h.n_tokens = idx->n_tokens;
     h.n_postings = idx->n_postings;
+    h.reserved[0] = (uint64_t)idx->dead.size();          // deleted positions follow the last array
     uint64_t vpool_bytes = 0;
     std::vector<uint64_t> vstart((size_t)idx->n_tokens);
     std::vector<uint32_t> vlen((size_t)idx->n_tokens);
@@ -740,6 +748,8 @@ int orr_index_save(orr_index *idx, const char *path)
     }
     if (r == ORR_OK && n) r = write_device_array(f, idx->d_post_off, sizeof(uint64_t) * (V + 1), buf);
     if (r == ORR_OK && idx->n_postings) r = write_device_array(f, idx->d_post_rows, sizeof(uint32_t) * (size_t)idx->n_postings, buf);
+    if (r == ORR_OK && !idx->dead.empty())
+        r = fwrite(idx->dead.data(), sizeof(int64_t), idx->dead.size(), f) == idx->dead.size() ? ORR_OK : fail(ORR_EINVAL, "short write");
     if (fclose(f) != 0 && r == ORR_OK) r = fail(ORR_EINVAL, "orr_index_save: close failed");
     return r;
 }
@@ -798,6 +808,16 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
         }
         ORR_TRY(dev_alloc(&idx->d_post_rows, std::max<size_t>((size_t)h.n_postings, 1)));
         if (h.n_postings) ORR_TRY(read_device_array(f, idx->d_post_rows, sizeof(uint32_t) * (size_t)h.n_postings, buf));
+        if (h.reserved[0]) {                          // deleted rows: norms and timestamps in the file are already overwritten
+            if (h.reserved[0] > (uint64_t)n) return fail(ORR_EINVAL, "shard file lists more deleted rows than rows");
+            idx->dead.resize((size_t)h.reserved[0]);
+            if (fread(idx->dead.data(), sizeof(int64_t), idx->dead.size(), f) != idx->dead.size()) return fail(ORR_EINVAL, "shard file is truncated");
+            for (size_t i = 0; i < idx->dead.size(); ++i)
+                if (idx->dead[i] < 0 || idx->dead[i] >= (int64_t)n || (i && idx->dead[i] <= idx->dead[i - 1]))
+                    return fail(ORR_EINVAL, "shard file has a malformed deleted-row list");
+            ORR_TRY(idx->d_dead.reserve(sizeof(int64_t) * idx->dead.size()));
+            HIP_TRY(hipMemcpy(idx->d_dead.p, idx->dead.data(), sizeof(int64_t) * idx->dead.size(), hipMemcpyHostToDevice));
+        }
         return ORR_OK;
     };
     r = body();
@@ -871,11 +891,70 @@ static int ensure_i8_shadow(orr_index *idx)
     return ORR_OK;
 }
 
+int64_t orr_index_live_rows(const orr_index *idx)
+{
+    return idx ? idx->n_rows - (int64_t)(idx->parent ? idx->parent->dead.size() : idx->dead.size()) : 0;
+}
+
+int orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int64_t *out_deleted)
+{
+    if (out_deleted) *out_deleted = 0;
+    if (!idx || n < 0 || (n > 0 && !row_ids)) return fail(ORR_EINVAL, "orr_index_delete_rows: bad argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_delete_rows: the index is not sealed");
+    if (idx->is_view) return fail(ORR_EINVAL, "orr_index_delete_rows: delete on the owning index, not on a view");
+    if (n == 0 || idx->n_rows == 0) return ORR_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    const size_t rows = (size_t)idx->n_rows;
+    if (idx->id_index.empty()) {                       // ids -> positions, once
+        std::vector<int64_t> ids(rows);
+        HIP_TRY(hipMemcpy(ids.data(), idx->d_row_ids, sizeof(int64_t) * rows, hipMemcpyDeviceToHost));
+        idx->id_index.resize(rows);
+        for (size_t p = 0; p < rows; ++p) idx->id_index[p] = {ids[p], (int64_t)p};
+        std::sort(idx->id_index.begin(), idx->id_index.end());
+    }
+    std::vector<int64_t> want((size_t)n);
+    HIP_TRY(hipMemcpy(want.data(), row_ids, sizeof(int64_t) * (size_t)n, hipMemcpyDefault));
+    std::vector<int64_t> fresh;
+    for (int64_t id : want) {
+        auto it = std::lower_bound(idx->id_index.begin(), idx->id_index.end(), std::make_pair(id, (int64_t)-1));
+        for (; it != idx->id_index.end() && it->first == id; ++it)
+            if (!std::binary_search(idx->dead.begin(), idx->dead.end(), it->second)) fresh.push_back(it->second);
+    }
+    std::sort(fresh.begin(), fresh.end());
+    fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+    if (fresh.empty()) return ORR_OK;
+    if ((idx->dead.size() + fresh.size()) * 4 > rows)
+        return fail(ORR_ESTATE, "orr_index_delete_rows: more than a quarter of the shard's %lld rows would be deleted: rebuild the shard",
+                    (long long)idx->n_rows);
+    std::vector<int64_t> merged(idx->dead.size() + fresh.size());
+    std::merge(idx->dead.begin(), idx->dead.end(), fresh.begin(), fresh.end(), merged.begin());
+    DevBuf tmp;
+    ORR_TRY(tmp.reserve(sizeof(int64_t) * fresh.size()));
+    int r = ORR_OK;
+    if (hipMemcpy(tmp.p, fresh.data(), sizeof(int64_t) * fresh.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        orr::launch_tombstone_rows(tmp.as<int64_t>(), (int32_t)fresh.size(), idx->d_norm_b, idx->d_created, idx->stream) != hipSuccess ||
+        hipStreamSynchronize(idx->stream) != hipSuccess)
+        r = fail(ORR_EDEVICE, "orr_index_delete_rows: device update failed");
+    tmp.release();
+    ORR_TRY(r);
+    ORR_TRY(idx->d_dead.reserve(sizeof(int64_t) * merged.size()));
+    HIP_TRY(hipMemcpy(idx->d_dead.p, merged.data(), sizeof(int64_t) * merged.size(), hipMemcpyHostToDevice));
+    idx->dead.swap(merged);
+    if (out_deleted) *out_deleted = (int64_t)fresh.size();
+    return ORR_OK;
+}
+
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
 {
     if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
     std::lock_guard<std::mutex> lock(idx->mu);
     if (strcmp(name, "fuse_epilogue") == 0) { idx->opt_fuse_epilogue = value != 0; return ORR_OK; }
+    if (strcmp(name, "dead_rows_before") == 0) {
+        if (value < 0) return fail(ORR_EINVAL, "orr_index_set_option: dead_rows_before must be >= 0");
+        idx->dead_before = value;
+        return ORR_OK;
+    }
     if (strcmp(name, "two_stage") == 0) {
         if (value < 0 || value > 2) return fail(ORR_EINVAL, "orr_index_set_option: two_stage takes 0, 1 or 2");
         idx->opt_two_stage = (int)value;
@@ -905,6 +984,7 @@ int orr_index_view(orr_index *parent, orr_index **out)
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
+    v->parent = parent; v->dead_before = parent->dead_before;
     v->device = parent->device; v->dim = parent->dim; v->row_base = parent->row_base;
     v->n_rows = parent->n_rows; v->cap_rows = parent->cap_rows;
     v->d_emb = parent->d_emb; v->d_created = parent->d_created; v->d_row_ids = parent->d_row_ids; v->d_norm_b = parent->d_norm_b;
@@ -999,6 +1079,8 @@ struct BatchArgs {
     mutable bool used_fused = false;
 };
 
+const orr_index *owner_of(const orr_index *idx) { return idx->parent ? idx->parent : idx; }
+
 int check_batch(const orr_index *idx, const BatchArgs &a, const char *fn)
 {
     if (!idx) return fail(ORR_EINVAL, "%s: null index", fn);
@@ -1011,11 +1093,18 @@ int check_batch(const orr_index *idx, const BatchArgs &a, const char *fn)
 }
 
 // Rows of this shard that take part: the global candidate prefix clipped to the shard.
+// Deleted rows do not count: the prefix ends behind the shard's local_live-th live row.
 int64_t participating_rows(const orr_index *idx, int64_t candidate_limit)
 {
     const int64_t limit = std::max<int64_t>(1, candidate_limit);     // Take(Math.Max(1, maxCount))
-    const int64_t local = limit - idx->row_base;
-    return std::max<int64_t>(0, std::min<int64_t>(local, idx->n_rows));
+    const int64_t local_live = limit - (idx->row_base - idx->dead_before);
+    if (local_live <= 0) return 0;
+    int64_t p = local_live;                                          // smallest p with p - dead(< p) == local_live
+    for (int64_t d : owner_of(idx)->dead) {
+        if (d < p) ++p; else break;
+        if (p >= idx->n_rows) break;
+    }
+    return std::min<int64_t>(p, idx->n_rows);
 }
 
 bool is_device_pointer(const void *p)
@@ -1596,6 +1685,9 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                     idx->d_row_ids, kw, b, 1, d_cand + (size_t)b * (kprime + 1), s));
         }
     }
+    if (!owner_of(idx)->dead.empty())      // records of deleted rows are dropped by the host finish
+        HIP_TRY(orr::launch_mark_dead_records(d_cand, B, kprime, owner_of(idx)->d_dead.as<int64_t>(),
+                                              (int32_t)owner_of(idx)->dead.size(), idx->row_base, s));
     HIP_TRY(hipStreamSynchronize(s));
     collect_events(idx);
     if (kw_overflow_possible) {
@@ -1632,6 +1724,7 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
         for (int32_t i = 0; i < tr.matches; ++i) {
             const orr_candidate &c = rec[i];
             if (c.row_id < 0 && c.order_key < 0) continue;
+            if (c.flags & ORR_CAND_DEAD) continue;                    // deleted row (orr_index_delete_rows)
             Ranked r;
             r.score = exact_score(c, use_cos, norm_a, n_terms, now_ticks);
             r.order_key = c.order_key;

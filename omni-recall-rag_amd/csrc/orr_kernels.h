@@ -224,5 +224,9 @@ hipError_t launch_gather_content(const uint8_t *src_pool, const uint64_t *src_st
                                  hipStream_t s);
 hipError_t launch_gather_u32(const uint32_t *src, uint32_t *dst, const int64_t *perm, int64_t n, hipStream_t s);
 hipError_t launch_iota_i64(int64_t *dst, int64_t n, int64_t base, hipStream_t s);
+// Deleted rows: overwrite norm and timestamp at the given positions; flag the records of deleted positions.
+hipError_t launch_tombstone_rows(const int64_t *pos, int32_t n, double *norm_b, int64_t *created, hipStream_t s);
+hipError_t launch_mark_dead_records(orr_candidate *recs, int32_t B, int32_t kprime, const int64_t *dead, int32_t n_dead,
+                                    int64_t row_base, hipStream_t s);
 
 }  // namespace orr

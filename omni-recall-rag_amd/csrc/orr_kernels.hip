@@ -805,6 +805,33 @@ __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restr
         dst[r] = src[perm[r]];
 }
 
+// ---- deleted rows (orr_index_delete_rows).  A deleted row keeps its position; its norm and timestamp are
+// overwritten so that it scores at most 0.2 (keyword part only) and its records are flagged for the host
+// finish, which drops them.
+__global__ void tombstone_rows_kernel(const int64_t *pos, int32_t n, double *norm_b, int64_t *created)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    norm_b[pos[i]] = 0.0;          // cosine 0 through the norm guard (:84)
+    created[pos[i]] = 0;           // year 1: exp(-age / 30) underflows to 0
+}
+
+__global__ void mark_dead_records_kernel(orr_candidate *recs, int64_t count, int32_t stride, const int64_t *dead,
+                                         int32_t n_dead, int64_t row_base)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count || (int32_t)(i % stride) == stride - 1) return;     // trailers stay as they are
+    const int64_t key = recs[i].order_key;
+    if (recs[i].row_id < 0 && key < 0) return;
+    const int64_t p = key - row_base;
+    int32_t lo = 0, hi = n_dead;                                       // dead[] ascending
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (dead[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n_dead && dead[lo] == p) recs[i].flags |= ORR_CAND_DEAD;
+}
+
 __global__ __launch_bounds__(256) void iota_i64_kernel(int64_t *__restrict__ dst, int64_t n, int64_t base)
 {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
@@ -854,6 +881,23 @@ hipError_t launch_iota_i64(int64_t *dst, int64_t n, int64_t base, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(iota_i64_kernel, dim3(capped_blocks(n, 256)), dim3(256), 0, s, dst, n, base);
+    return hipGetLastError();
+}
+
+hipError_t launch_tombstone_rows(const int64_t *pos, int32_t n, double *norm_b, int64_t *created, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tombstone_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, norm_b, created);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_dead_records(orr_candidate *recs, int32_t B, int32_t kprime, const int64_t *dead, int32_t n_dead,
+                                    int64_t row_base, hipStream_t s)
+{
+    const int64_t count = (int64_t)B * (kprime + 1);
+    if (count <= 0 || n_dead <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_dead_records_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, recs, count, kprime + 1,
+                       dead, n_dead, row_base);
     return hipGetLastError();
 }
 

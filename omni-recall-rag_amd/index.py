@@ -118,6 +118,18 @@ class RecallIndex:
     def seal(self) -> None:
         N.check(N.hip.orr_index_seal(self._h))
 
+    def delete_rows(self, row_ids) -> int:
+        """orr_index_delete_rows: the rows with these ids stop taking part in later searches (no reseal).
+        Returns how many rows were newly deleted."""
+        ids = np.ascontiguousarray(row_ids, dtype=np.int64).reshape(-1)
+        done = C.c_int64(0)
+        N.check(N.hip.orr_index_delete_rows(self._h, int(ids.shape[0]), _ptr(ids), C.cast(C.byref(done), C.c_void_p)))
+        return int(done.value)
+
+    @property
+    def live_rows(self) -> int:
+        return int(N.hip.orr_index_live_rows(self._h))
+
     def save(self, path: str) -> None:
         """orr_index_save: the sealed shard as one binary file."""
         N.check(N.hip.orr_index_save(self._h, path.encode()))

@@ -194,7 +194,8 @@ def test_chat_evidence_guard_consumer_sees_the_same_scores():
 def test_uploads_after_the_first_build_become_delta_shards():
     """newer documents are indexed as small delta shards in front of the existing ones
     (no full rebuild); searches over several shards stay identical to the oracle over the whole store;
-    deletes and out-of-order timestamps fall back to a rebuild."""
+    deletes and replaced chunk lists drop rows in place (orr_index_delete_rows); out-of-order timestamps
+    and deleting more than a quarter of a shard fall back to a rebuild."""
     S = _svc()
     rng = np.random.default_rng(31)
     store = S.InMemoryIngestionStore()
@@ -207,6 +208,14 @@ def test_uploads_after_the_first_build_become_delta_shards():
                                   rng.standard_normal(16).astype(np.float32), created) for i in range(n_chunks)]
         store.UpsertChunks(cs)
         chunks_flat.extend(cs)
+
+    def replace(doc, created, n_chunks):
+        at = next(i for i, c in enumerate(chunks_flat) if c.DocumentId == doc)      # the document keeps its place in the enumeration
+        chunks_flat[:] = [c for c in chunks_flat if c.DocumentId != doc]
+        tail = chunks_flat[at:]
+        del chunks_flat[at:]
+        upload(doc, created, n_chunks)
+        chunks_flat.extend(tail)
 
     def check(sut, k=8):
         cor = orc.OracleCorpus([c.Embedding for c in chunks_flat], [c.CreatedAtTicks for c in chunks_flat],
@@ -224,7 +233,7 @@ def test_uploads_after_the_first_build_become_delta_shards():
     for sut_limit in (300, 10**6):
         sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=sut_limit, now_ticks=NOW)
         check(sut)
-        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0}
+        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0, "tombstoned_rows": 0}
         t = base_time + 10**9 * (1 if sut_limit == 300 else 5)
         for step in range(3):                                  # three rounds of newer uploads -> three delta shards
             for j in range(2):
@@ -236,13 +245,31 @@ def test_uploads_after_the_first_build_become_delta_shards():
         upload("late-%d" % sut_limit, base_time - 5)            # older than what is indexed: order would break -> rebuild
         check(sut)
         assert sut.Stats()["shards"] == 1 and sut.Stats()["full_rebuilds"] == 2
-        store.DeleteDocument("old-03")                          # delete -> rebuild
+        store.DeleteDocument("old-03")                          # delete -> its rows are dropped in place, no rebuild
         chunks_flat[:] = [c for c in chunks_flat if c.DocumentId != "old-03"]
         check(sut)
-        assert sut.Stats()["full_rebuilds"] == 3
+        st = sut.Stats()
+        assert st["full_rebuilds"] == 2 and st["shards"] == 1 and st["tombstoned_rows"] == 6, st
+        # reindex (DocumentIngestionService.cs:210-291): a document's chunk list is replaced by a newer one ->
+        # the old rows are dropped in place and the new list becomes a delta shard
+        prev = sum(1 for c in chunks_flat if c.DocumentId == "old-05")
+        t += 10**7
+        replace("old-05", t, 4)
+        check(sut)
+        st = sut.Stats()
+        assert st["full_rebuilds"] == 2 and st["shards"] == 2 and st["tombstoned_rows"] == 6 + prev, st
+        check(sut, k=300)                                       # more than the live rows inside candidate_limit
+        gone = ["old-%02d" % d for d in range(6, 20)]           # more than a quarter of a shard at once: rebuild
+        for g in gone:
+            store.DeleteDocument(g)
+        chunks_flat[:] = [c for c in chunks_flat if c.DocumentId not in gone]
+        check(sut)
+        assert sut.Stats()["full_rebuilds"] == 3 and sut.Stats()["shards"] == 1
         sut.close()
         # restore for the second pass
         upload("old-03", base_time + 3 * 1000 + 1)
+        for g in gone:
+            upload(g, base_time + int(g[4:]) * 1000 + 1)
     store.close()
 
 
