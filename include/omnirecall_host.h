@@ -79,6 +79,25 @@ int orrh_store_upsert_chunks(orrh_store *s, const char *document_id, int32_t n, 
 int orrh_store_delete_document(orrh_store *s, const char *document_id);
 int64_t orrh_store_chunk_count(const orrh_store *s);
 
+/* ---- the reference's durable corpus format -------------------------------------
+ * Cosmos items as System.Text.Json writes them under JsonNamingPolicy.CamelCase
+ * (CosmosIngestionRecords.cs:5-30, CosmosIngestionStore.cs:34-40):
+ *   {"id","PartitionKey","type":"chunk","documentId","chunkIndex","content","embedding":[..]|null,"createdAtUtc"}
+ *   {"id","PartitionKey","type":"document","fileName",...,"createdAtUtc"}
+ * Input: a JSON array of items, or items one after another (JSON lines), or query pages
+ * {"Documents":[...],"_count":n} back to back; system properties (_rid, _etag, _ts ...) and unknown ones
+ * are ignored, names are case-sensitive, the last duplicate property wins.  "embedding" numbers are read
+ * straight to binary32, correctly rounded; "createdAtUtc" is ISO 8601 (Z or +-hh:mm, up to 100 ns).
+ * Documents are upserted (UpsertDocumentAsync); the chunk items of one documentId become that document's
+ * chunk list (UpsertChunksAsync: ordered by chunkIndex, replacing what the store held; a repeated item id
+ * replaces the earlier item).  The input is parsed and validated completely before the store changes:
+ * ORR_EINVAL leaves it untouched.  Export writes the store in the same form (documents, then chunks in
+ * enumeration order; floats in their shortest round-trip text; release with orrh_free): import(export(s))
+ * rebuilds an identical store. */
+int orrh_store_import_cosmos_json(orrh_store *s, const uint8_t *json, int64_t len, int64_t *out_documents,
+                                  int64_t *out_chunks);
+int orrh_store_export_cosmos_json(orrh_store *s, uint8_t **out_json, int64_t *out_len);
+
 /* candidate_limit = GetRecentChunksAsync(maxCount) (300 in the reference). */
 orrh_service *orrh_service_create(orrh_store *s, int32_t device, int64_t candidate_limit);
 void          orrh_service_destroy(orrh_service *svc);

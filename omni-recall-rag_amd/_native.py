@@ -120,6 +120,10 @@ host.orrh_store_upsert_chunks.restype = C.c_int
 host.orrh_store_upsert_chunks.argtypes = [_vp, C.c_char_p, _i32, _vp, _vp, _vp, _vp, _vp, _vp]
 host.orrh_store_delete_document.restype = C.c_int
 host.orrh_store_delete_document.argtypes = [_vp, C.c_char_p]
+host.orrh_store_import_cosmos_json.restype = C.c_int
+host.orrh_store_import_cosmos_json.argtypes = [_vp, C.c_char_p, _i64, _vp, _vp]
+host.orrh_store_export_cosmos_json.restype = C.c_int
+host.orrh_store_export_cosmos_json.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_i64)]
 host.orrh_store_chunk_count.restype = _i64
 host.orrh_store_chunk_count.argtypes = [_vp]
 host.orrh_service_create.restype = _vp
@@ -161,7 +165,7 @@ EXPORTED_HIP_SYMBOLS = [
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
-                         "orrh_store_chunk_count", "orrh_service_create", "orrh_service_destroy",
+                         "orrh_store_chunk_count", "orrh_store_import_cosmos_json", "orrh_store_export_cosmos_json", "orrh_service_create", "orrh_service_destroy",
                          "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
                          "orrh_batcher_search", "orrh_batcher_stats"]
 

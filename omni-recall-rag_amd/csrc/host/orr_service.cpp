@@ -16,33 +16,74 @@
 #include "../../../include/omnirecall_hip.h"
 #include "../../../include/omnirecall_host.h"
 
-namespace {
+#include "orr_store.h"
 
+namespace orrh_detail {
 thread_local std::string g_err;
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}  // namespace orrh_detail
 
-struct Chunk {                      // CosmosChunkRecord (CosmosIngestionRecords.cs:19-30)
-    std::string id, document_id, content;
-    int32_t chunk_index = 0;
-    std::vector<float> embedding;   // empty = null
-    int64_t created_ticks = 0;
-};
-struct Document {                   // CosmosDocumentRecord, the fields the path reads
-    std::string id, file_name;
-    int64_t created_ticks = 0;
-};
+namespace orrh_detail {
 
-}  // namespace
+void json_string(const std::string &s, std::string &out)
+{
+    out.push_back('"');
+    for (unsigned char c : s) {
+        switch (c) {
+        case '"': out += "\\\""; break;
+        case '\\': out += "\\\\"; break;
+        case '\n': out += "\\n"; break;
+        case '\r': out += "\\r"; break;
+        case '\t': out += "\\t"; break;
+        case '\b': out += "\\b"; break;
+        case '\f': out += "\\f"; break;
+        default:
+            if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04X", c); out += b; }
+            else out.push_back((char)c);
+        }
+    }
+    out.push_back('"');
+}
 
-struct orrh_store {
-    std::mutex mu;
-    std::vector<std::string> doc_order;                 // enumeration order of _chunksByDocument
-    std::map<std::string, Document> documents;
-    std::map<std::string, std::vector<Chunk>> chunks_by_document;
-    std::map<std::string, uint64_t> chunk_stamp;        // document -> version of its current chunk list
-    uint64_t version = 0;                               // any change
-    uint64_t chunks_version = 0;                        // changes the index has to follow
-};
+// DateTime (Kind=Utc) as System.Text.Json writes it: yyyy-MM-ddTHH:mm:ss[.fffffff]Z
+std::string iso_utc(int64_t ticks)
+{
+    const int64_t tps = 10000000;
+    int64_t secs = ticks / tps, frac = ticks % tps;
+    int64_t days = secs / 86400, sod = secs % 86400;
+    // days since 0001-01-01 -> civil date (proleptic Gregorian)
+    int64_t z = days + 306;                       // shift so the era starts on 0000-03-01
+    int64_t era = z / 146097, doe = z % 146097;
+    int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    int64_t y = yoe + era * 400;
+    int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    int64_t mp = (5 * doy + 2) / 153;
+    int64_t d = doy - (153 * mp + 2) / 5 + 1;
+    int64_t m = mp < 10 ? mp + 3 : mp - 9;
+    if (m <= 2) y += 1;
+    char buf[64];
+    int n = snprintf(buf, sizeof(buf), "%04lld-%02lld-%02lldT%02lld:%02lld:%02lld", (long long)y, (long long)m,
+                     (long long)d, (long long)(sod / 3600), (long long)((sod / 60) % 60), (long long)(sod % 60));
+    std::string out(buf, (size_t)n);
+    if (frac) {
+        char f[16];
+        snprintf(f, sizeof(f), ".%07lld", (long long)frac);
+        std::string fs(f);
+        while (fs.back() == '0') fs.pop_back();
+        out += fs;
+    }
+    out.push_back('Z');
+    return out;
+}
+
+}  // namespace orrh_detail
+
+using orrh_detail::Chunk;
+using orrh_detail::Document;
+using orrh_detail::fail;
+using orrh_detail::g_err;
+using orrh_detail::iso_utc;
+using orrh_detail::json_string;
 
 struct Shard {                       // one sealed orr_index and the chunks behind its row ids
     orr_index *index = nullptr;
@@ -77,63 +118,12 @@ std::string lower(const std::string &s)
     return out;
 }
 
-void json_string(const std::string &s, std::string &out)
-{
-    out.push_back('"');
-    for (unsigned char c : s) {
-        switch (c) {
-        case '"': out += "\\\""; break;
-        case '\\': out += "\\\\"; break;
-        case '\n': out += "\\n"; break;
-        case '\r': out += "\\r"; break;
-        case '\t': out += "\\t"; break;
-        case '\b': out += "\\b"; break;
-        case '\f': out += "\\f"; break;
-        default:
-            if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04X", c); out += b; }
-            else out.push_back((char)c);
-        }
-    }
-    out.push_back('"');
-}
-
 void json_double(double v, std::string &out)
 {
     if (std::isnan(v) || std::isinf(v)) { out += "null"; return; }     // System.Text.Json would throw
     char buf[64];
     auto r = std::to_chars(buf, buf + sizeof(buf), v);                 // shortest round-trip, like .NET "R"
     out.append(buf, r.ptr);
-}
-
-// DateTime (Kind=Utc) as System.Text.Json writes it: yyyy-MM-ddTHH:mm:ss[.fffffff]Z
-std::string iso_utc(int64_t ticks)
-{
-    const int64_t tps = 10000000;
-    int64_t secs = ticks / tps, frac = ticks % tps;
-    int64_t days = secs / 86400, sod = secs % 86400;
-    // days since 0001-01-01 -> civil date (proleptic Gregorian)
-    int64_t z = days + 306;                       // shift so the era starts on 0000-03-01
-    int64_t era = z / 146097, doe = z % 146097;
-    int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
-    int64_t y = yoe + era * 400;
-    int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
-    int64_t mp = (5 * doy + 2) / 153;
-    int64_t d = doy - (153 * mp + 2) / 5 + 1;
-    int64_t m = mp < 10 ? mp + 3 : mp - 9;
-    if (m <= 2) y += 1;
-    char buf[64];
-    int n = snprintf(buf, sizeof(buf), "%04lld-%02lld-%02lldT%02lld:%02lld:%02lld", (long long)y, (long long)m,
-                     (long long)d, (long long)(sod / 3600), (long long)((sod / 60) % 60), (long long)(sod % 60));
-    std::string out(buf, (size_t)n);
-    if (frac) {
-        char f[16];
-        snprintf(f, sizeof(f), ".%07lld", (long long)frac);
-        std::string fs(f);
-        while (fs.back() == '0') fs.pop_back();
-        out += fs;
-    }
-    out.push_back('Z');
-    return out;
 }
 
 void free_shards(orrh_service *svc)

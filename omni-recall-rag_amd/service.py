@@ -69,6 +69,24 @@ class InMemoryIngestionStore:
     def ChunkCount(self) -> int:
         return int(N.host.orrh_store_chunk_count(self._h))
 
+    def ImportCosmosJson(self, data) -> tuple:
+        """orrh_store_import_cosmos_json: Cosmos-style camelCase items (array, JSON lines or query pages).
+        Returns (documents, chunks) upserted; HostError(ORR_EINVAL) leaves the store untouched."""
+        raw = data.encode("utf-8") if isinstance(data, str) else bytes(data)
+        nd, nc = C.c_int64(0), C.c_int64(0)
+        _check(N.host.orrh_store_import_cosmos_json(self._h, raw, len(raw), C.cast(C.byref(nd), C.c_void_p),
+                                                    C.cast(C.byref(nc), C.c_void_p)))
+        return int(nd.value), int(nc.value)
+
+    def ExportCosmosJson(self) -> bytes:
+        """orrh_store_export_cosmos_json: the store as a JSON array of Cosmos-style items."""
+        out, ln = C.c_void_p(), C.c_int64()
+        _check(N.host.orrh_store_export_cosmos_json(self._h, C.byref(out), C.byref(ln)))
+        try:
+            return C.string_at(out, ln.value)
+        finally:
+            N.host.orrh_free(out)
+
     def close(self):
         if self._h:
             N.host.orrh_store_destroy(self._h)
