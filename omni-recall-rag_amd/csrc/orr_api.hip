@@ -151,6 +151,10 @@ struct orr_index {
     uint64_t *d_post_off = nullptr;    // [n_tokens+1]
     uint32_t *d_post_rows = nullptr;   // ascending candidate positions per token
     uint64_t n_postings = 0;
+    // vocabulary tokens longer than 16 bytes (URLs and the like) go through the wave-per-token scan; the rest is
+    // matched one lane per token.  Built at the first search with terms (ensure_vlong); -1 = not yet.
+    int64_t n_vlong = -1;
+    DevBuf vlong_start, vlong_len, vlong_id;
     std::vector<int64_t> h_created;    // host mirror (seal-time ordering)
     std::vector<uint32_t> h_clen;      // host mirror of content lengths
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
@@ -460,6 +464,7 @@ void orr_index_destroy(orr_index *idx)
         for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat, &idx->i8_rowf}) { b->p = nullptr; b->cap = 0; }
     }
     idx->d_dead.release();
+    if (!idx->is_view) { idx->vlong_start.release(); idx->vlong_len.release(); idx->vlong_id.release(); }
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
@@ -891,6 +896,31 @@ static int ensure_i8_shadow(orr_index *idx)
     return ORR_OK;
 }
 
+// The long tokens of the vocabulary as their own row list for the wave-per-token scan.
+static int ensure_vlong(orr_index *idx)
+{
+    if (idx->n_vlong >= 0 || idx->is_view) return ORR_OK;          // a view copies its parent's at creation
+    const size_t V = (size_t)idx->n_tokens;
+    std::vector<uint64_t> start, vstart(V);
+    std::vector<uint32_t> len, id, vlen(V);
+    if (V) {
+        HIP_TRY(hipMemcpy(vstart.data(), idx->d_vstart, sizeof(uint64_t) * V, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(vlen.data(), idx->d_vlen, sizeof(uint32_t) * V, hipMemcpyDeviceToHost));
+    }
+    for (size_t v = 0; v < V; ++v)
+        if (vlen[v] > 16) { start.push_back(vstart[v]); len.push_back(vlen[v]); id.push_back((uint32_t)v); }
+    if (!id.empty()) {
+        ORR_TRY(idx->vlong_start.reserve(sizeof(uint64_t) * id.size()));
+        ORR_TRY(idx->vlong_len.reserve(sizeof(uint32_t) * id.size()));
+        ORR_TRY(idx->vlong_id.reserve(sizeof(uint32_t) * id.size()));
+        HIP_TRY(hipMemcpy(idx->vlong_start.p, start.data(), sizeof(uint64_t) * id.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(idx->vlong_len.p, len.data(), sizeof(uint32_t) * id.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(idx->vlong_id.p, id.data(), sizeof(uint32_t) * id.size(), hipMemcpyHostToDevice));
+    }
+    idx->n_vlong = (int64_t)id.size();
+    return ORR_OK;
+}
+
 int64_t orr_index_live_rows(const orr_index *idx)
 {
     return idx ? idx->n_rows - (int64_t)(idx->parent ? idx->parent->dead.size() : idx->dead.size()) : 0;
@@ -984,6 +1014,9 @@ int orr_index_view(orr_index *parent, orr_index **out)
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
+    ORR_TRY(ensure_vlong(parent));
+    v->n_vlong = parent->n_vlong;
+    v->vlong_start.p = parent->vlong_start.p; v->vlong_len.p = parent->vlong_len.p; v->vlong_id.p = parent->vlong_id.p;   // borrowed
     v->parent = parent; v->dead_before = parent->dead_before;
     v->device = parent->device; v->dim = parent->dim; v->row_base = parent->row_base;
     v->n_rows = parent->n_rows; v->cap_rows = parent->cap_rows;
@@ -1347,7 +1380,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const size_t off_terms = 0;
         const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
         const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
-        const size_t off_pool = off_iota + sizeof(uint32_t) * 65;
+        const size_t off_match = off_iota + sizeof(uint32_t) * 65;
+        const size_t off_pool = off_match + sizeof(orr::MatchTerm) * TT;
         const size_t meta_bytes = off_pool + pool_bytes + 16;
         ORR_TRY(idx->pin_meta.reserve(meta_bytes));
         ORR_TRY(idx->ws_meta.reserve(meta_bytes));
@@ -1364,6 +1398,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             }
             st[t].prefix = pre;
             st[t].mask = msk;
+            orr::MatchTerm &mt = reinterpret_cast<orr::MatchTerm *>(hm + off_match)[t];
+            memset(&mt, 0, sizeof(mt));
+            mt.len = st[t].len;
+            for (uint32_t k = 0; k < 16 && k < st[t].len; ++k) {
+                mt.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
+                mt.m[k >> 2] |= 0xFFu << (8 * (k & 3));
+            }
             memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
             cursor += st[t].len;
         }
@@ -1375,7 +1416,9 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
         const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
         const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, 16u << 20);
-        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(V, 1)));
+        ORR_TRY(ensure_vlong(idx));
+        const int64_t VL = idx->n_vlong;
+        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
         ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
         ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
         ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
@@ -1386,15 +1429,24 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
         if (V > 0) {
             const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
-            {   // every distinct term is its own 1-term "query"; all groups of 64 terms in one launch
-                Timed t(idx, "vocab_scan", 0.0, k);
-                HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->d_vstart, idx->d_vlen, V, dm + off_pool, d_terms, (int32_t)TT,
-                                               reinterpret_cast<const uint32_t *>(dm + off_iota), idx->ws_vmatch.as<uint16_t>(), k));
+            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
+                Timed t(idx, "vocab_match", 0.0, k);
+                HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
+                                                      reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
+                                                      idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
             }
-            {
-                Timed t(idx, "vocab_hits", 0.0, k);
-                HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), V, (int32_t)TT, idx->d_post_off,
-                                               idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+            if (VL > 0) {   // longer tokens: every distinct term is its own 1-term "query" of the wave-per-token scan
+                {
+                    Timed t(idx, "vocab_scan", 0.0, k);
+                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(), VL,
+                                                   dm + off_pool, d_terms, (int32_t)TT, reinterpret_cast<const uint32_t *>(dm + off_iota),
+                                                   idx->ws_vmatch.as<uint16_t>(), k));
+                }
+                {
+                    Timed t(idx, "vocab_hits", 0.0, k);
+                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VL, (int32_t)TT, idx->vlong_id.as<uint32_t>(), idx->d_post_off,
+                                                   idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+                }
             }
             {
                 Timed t(idx, "expand_hits", 0.0, k);

@@ -77,8 +77,21 @@ struct KwHit {
 };
 constexpr uint32_t kPostChunk = 1024;
 
-hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n_terms, const uint64_t *post_off,
-                             unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
+// token_ids != nullptr: the scanned rows were the vocabulary tokens token_ids[0..n_tokens) (the long ones)
+hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n_terms, const uint32_t *token_ids,
+                             const uint64_t *post_off, unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
+
+// A query term for the lane-per-token matcher: its first 16 bytes as dwords with byte masks.
+struct MatchTerm {
+    uint32_t w[4], m[4];
+    uint32_t len;       // bytes; terms longer than 16 bytes cannot occur in the tokens this kernel covers
+    uint32_t pad[3];
+};
+constexpr int kMatchGroup = 32;       // terms per workgroup (grid.y)
+// Every token of at most 16 bytes against every term, hits reserved as by launch_vocab_hits.
+hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
+                                    const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
+                                    unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
 hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
                               const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s);
 

@@ -369,14 +369,17 @@ hipError_t launch_vocab_scan(const uint8_t *vpool, const uint64_t *vstart, const
 // postings per step, one atomicOr each into the term's row bitmap.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vocab_hits_kernel(const uint16_t *__restrict__ vmatch, int64_t n_tokens,
-                                                         int32_t n_terms, const uint64_t *__restrict__ post_off,
+                                                         int32_t n_terms, const uint32_t *__restrict__ token_ids,
+                                                         const uint64_t *__restrict__ post_off,
                                                          unsigned long long *__restrict__ counter,
                                                          KwHit *__restrict__ hits, uint32_t max_hits)
 {
     const int64_t total = n_tokens * (int64_t)n_terms;
     for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
         if (vmatch[id] == 0) continue;                       // vmatch is [term][token]
-        const int64_t t = id / n_tokens, v = id - t * n_tokens;
+        const int64_t t = id / n_tokens;
+        int64_t v = id - t * n_tokens;
+        if (token_ids) v = token_ids[v];                     // the scanned rows were a subset of the vocabulary
         const uint64_t p0 = post_off[v], p1 = post_off[v + 1];
         const uint32_t chunks = (uint32_t)((p1 - p0 + kPostChunk - 1) / kPostChunk);
         const unsigned long long old = atomicAdd(counter, (1ull << 32) | chunks);
@@ -430,14 +433,91 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restric
     }
 }
 
-hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n_terms, const uint64_t *post_off,
-                             unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s)
+hipError_t launch_vocab_hits(const uint16_t *vmatch, int64_t n_tokens, int32_t n_terms, const uint32_t *token_ids,
+                             const uint64_t *post_off, unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s)
 {
     if (n_tokens <= 0 || n_terms <= 0) return hipSuccess;
     int64_t blocks = (n_tokens * (int64_t)n_terms + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(vocab_hits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vmatch, n_tokens, n_terms, post_off,
+    hipLaunchKernelGGL(vocab_hits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vmatch, n_tokens, n_terms, token_ids, post_off,
                        counter, hits, max_hits);
+    return hipGetLastError();
+}
+
+// Vocabulary tokens of at most 16 bytes (all but URLs and the like): ONE LANE per token instead of one wave.
+// The lane keeps its token's 16 four-byte windows in registers; the terms of the block's group are uniform
+// (scalar loads), each as up to four dwords with byte masks.  A term occurs in the token iff at some start i
+// with i + len(term) <= len(token) every dword of the term equals the window at i + 4j under its mask; bytes
+// past the token are padding and never take part.  A hit reserves its slot like vocab_hits does.
+__global__ __launch_bounds__(256) void vocab_match_short_kernel(const uint8_t *__restrict__ vpool,
+                                                                const uint64_t *__restrict__ vstart,
+                                                                const uint32_t *__restrict__ vlen, int64_t n_tokens,
+                                                                const MatchTerm *__restrict__ terms, int32_t n_terms,
+                                                                const uint64_t *__restrict__ post_off,
+                                                                unsigned long long *__restrict__ counter,
+                                                                KwHit *__restrict__ hits, uint32_t max_hits)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int32_t t0 = (int32_t)blockIdx.y * kMatchGroup;
+    const int32_t t1 = n_terms < t0 + kMatchGroup ? n_terms : t0 + kMatchGroup;
+    int32_t len = 0;
+    uint4 w = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
+    if (v < n_tokens) {
+        const uint32_t l = vlen[v];
+        if (l >= 1 && l <= 16) { len = (int32_t)l; w = *reinterpret_cast<const uint4 *>(vpool + vstart[v]); }   // rows start 16-byte aligned
+    }
+    const uint32_t w4 = 0x20202020u;
+    uint32_t win[16];
+    win[0] = w.x;  win[1] = __builtin_amdgcn_alignbyte(w.y, w.x, 1);
+    win[2] = __builtin_amdgcn_alignbyte(w.y, w.x, 2);  win[3] = __builtin_amdgcn_alignbyte(w.y, w.x, 3);
+    win[4] = w.y;  win[5] = __builtin_amdgcn_alignbyte(w.z, w.y, 1);
+    win[6] = __builtin_amdgcn_alignbyte(w.z, w.y, 2);  win[7] = __builtin_amdgcn_alignbyte(w.z, w.y, 3);
+    win[8] = w.z;  win[9] = __builtin_amdgcn_alignbyte(w.w, w.z, 1);
+    win[10] = __builtin_amdgcn_alignbyte(w.w, w.z, 2); win[11] = __builtin_amdgcn_alignbyte(w.w, w.z, 3);
+    win[12] = w.w; win[13] = __builtin_amdgcn_alignbyte(w4, w.w, 1);
+    win[14] = __builtin_amdgcn_alignbyte(w4, w.w, 2);  win[15] = __builtin_amdgcn_alignbyte(w4, w.w, 3);
+
+    for (int32_t t = t0; t < t1; ++t) {
+        const uint32_t tlen = (uint32_t)uniform32((int)terms[t].len);
+        if (tlen == 0 || tlen > 16) continue;                     // longer terms only fit longer tokens
+        const uint32_t w0 = (uint32_t)uniform32((int)terms[t].w[0]), m0 = (uint32_t)uniform32((int)terms[t].m[0]);
+        uint32_t cand = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cand |= ((win[i] & m0) == w0) ? (1u << i) : 0u;
+        const int32_t last = len - (int32_t)tlen;                 // last start that keeps the term inside the token
+        cand = last < 0 ? 0u : (cand & ((2u << last) - 1u));
+        if (__ballot(cand != 0u) == 0ull) continue;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            if (tlen <= 4u * j) break;
+            const uint32_t wj = (uint32_t)uniform32((int)terms[t].w[j]), mj = (uint32_t)uniform32((int)terms[t].m[j]);
+#pragma unroll
+            for (int i = 0; i + 4 * j < 16; ++i)
+                if ((win[i + 4 * j] & mj) != wj) cand &= ~(1u << i);
+        }
+        if (cand == 0u) continue;
+        const uint64_t p0 = post_off[v], p1 = post_off[v + 1];
+        const uint32_t chunks = (uint32_t)((p1 - p0 + kPostChunk - 1) / kPostChunk);
+        const unsigned long long old = atomicAdd(counter, (1ull << 32) | chunks);
+        const uint32_t slot = (uint32_t)(old >> 32);
+        if (slot < max_hits) {
+            KwHit h;
+            h.post_begin = p0; h.post_end = p1; h.chunk_base = (uint32_t)old; h.term = (uint32_t)t;
+            hits[slot] = h;
+        }
+    }
+}
+
+hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
+                                    const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
+                                    unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s)
+{
+    if (n_tokens <= 0 || n_terms <= 0) return hipSuccess;
+    const int64_t blocks = (n_tokens + 255) / 256;
+    const int32_t groups = (n_terms + kMatchGroup - 1) / kMatchGroup;
+    if (groups > 65535 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vocab_match_short_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, s, vpool, vstart, vlen,
+                       n_tokens, terms, n_terms, post_off, counter, hits, max_hits);
     return hipGetLastError();
 }
 

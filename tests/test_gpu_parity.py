@@ -157,6 +157,50 @@ def test_long_contents_and_many_terms():
     idx.close()
 
 
+def test_keyword_terms_against_tokens_of_every_length():
+    """The token index matches short vocabulary tokens (<= 16 bytes) one lane per token and longer ones one
+    wave per token: terms of 1..40 bytes at every offset of tokens of 1..40 bytes, incl. the 4-, 8-, 12- and
+    16-byte edges, multi-byte UTF-8, and terms that only almost match.  No embeddings: the score is the
+    keyword fraction plus recency, so every row's match count is compared through the ranking."""
+    rng = np.random.default_rng(13)
+    alphabet = list("abcdefghijklmnopqrstuvwxyz0123456789-_.:/") + ["é", "ß", "中", "🚀"]
+    tokens = []
+    for ln in list(range(1, 41)) * 6:
+        tokens.append("".join(rng.choice(alphabet, size=ln)))
+    tokens += ["a" * 16, "a" * 17, "ab" * 8, "ab" * 9, "abcdefghijklmnop", "abcdefghijklmnopq", "xabcdefghijklmnop"]
+    n = 900
+    contents = [" ".join(rng.choice(tokens, size=int(rng.integers(1, 9)))) for _ in range(n)]
+    created = (NOW - rng.integers(0, 100 * DAY, n)).astype(np.int64)
+    c = {"emb": [None] * n, "created": created, "contents": contents, "dim": 0}
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    P = pkg()
+    queries = []
+    for _ in range(60):
+        terms = []
+        for _ in range(int(rng.integers(1, 6))):
+            tok = tokens[int(rng.integers(0, len(tokens)))]
+            a = int(rng.integers(0, len(tok)))
+            b = int(rng.integers(a + 1, len(tok) + 1))
+            term = tok[a:b]
+            if rng.random() < 0.25:                          # break it somewhere: must not match by its prefix alone
+                k = int(rng.integers(0, len(term)))
+                term = term[:k] + "#" + term[k + 1:]
+            terms.append(term)
+        queries.append(" ".join(terms))
+    queries += ["a" * 16, "a" * 17, "a" * 15 + "b", "abcdefghijklmnop", "bcdefghijklmnopq", "abcdefghijklmnopq", "mnop", "mnopq",
+                "ab" * 8, "ba" * 8, "é", "中🚀", "-", "🚀"]
+    for text in queries:
+        assert_same_ranking(idx, corpus, c, None, text, n, n)
+    # the same through one batch (distinct terms are matched once for all queries)
+    terms = [P.text.query_terms(t) for t in queries]
+    rows, scores, counts = idx.search(None, terms, NOW, 25, candidate_limit=n)
+    for b, text in enumerate(queries):
+        orow, osc, _ = corpus.search([], text, NOW, 25, candidate_limit=n)
+        assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), text
+    idx.close()
+
+
 def test_batched_queries_equal_single_queries():
     P = pkg()
     rng = np.random.default_rng(21)
