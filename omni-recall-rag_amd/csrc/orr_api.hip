@@ -12,6 +12,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -175,10 +179,10 @@ struct orr_index {
     std::vector<std::pair<int64_t, int64_t>> id_index;   // (row id, position) ascending, built at the first delete
 
     // search workspace
-    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero;
+    DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero, ws_norm_a;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
-    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand;
+    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm;
     hipEvent_t ev_q = nullptr;
 
     // profiling
@@ -322,9 +326,78 @@ double exact_norm(const float *q, int32_t dim)
     return acc;
 }
 
+// A few persistent host threads for the per-query work around a batch (exact norms of host-resident queries, the
+// host finish): queries are independent, and starting threads per call costs more than the work of a small batch.
+// One parallel region at a time; a second caller (another search lane) simply runs its tasks itself.
+class HostPool {
+public:
+    static HostPool &get()
+    {
+        static HostPool *pool = new HostPool((int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) - 1);
+        return *pool;                                  // never destroyed: its threads sleep until the process ends
+    }
+    int width() const { return (int)workers_.size() + 1; }
+    void run(int n_tasks, const std::function<void(int)> &fn)
+    {
+        std::unique_lock<std::mutex> region(region_mu_, std::try_to_lock);
+        if (!region.owns_lock() || workers_.empty() || n_tasks <= 1) {
+            for (int i = 0; i < n_tasks; ++i) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            fn_ = &fn; n_tasks_ = n_tasks; next_.store(0); active_ = (int)workers_.size(); ++generation_;
+        }
+        cv_work_.notify_all();
+        for (int i; (i = next_.fetch_add(1)) < n_tasks;) fn(i);
+        std::unique_lock<std::mutex> l(mu_);
+        cv_done_.wait(l, [&] { return active_ == 0; });
+    }
+
+private:
+    explicit HostPool(int n_workers)
+    {
+        for (int i = 0; i < n_workers; ++i) workers_.emplace_back([this] { loop(); });
+        for (auto &w : workers_) w.detach();
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_work_.wait(l, [&] { return generation_ != seen; });
+            seen = generation_;
+            const std::function<void(int)> *fn = fn_;
+            const int n = n_tasks_;
+            l.unlock();
+            for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+            l.lock();
+            if (--active_ == 0) cv_done_.notify_one();
+        }
+    }
+    std::mutex region_mu_, mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_tasks_ = 0, active_ = 0;
+    std::atomic<int> next_{0};
+    uint64_t generation_ = 0;
+};
+
 // The same sums for a batch.  Each query's sum is a chain of dependent fp64 additions (the order is
 // part of the reference's arithmetic), so eight queries are walked in lock step to keep the adder busy.
+void exact_norms_range(const float *q, int32_t B, int32_t dim, double *out);
 void exact_norms(const float *q, int32_t B, int32_t dim, double *out)
+{
+    if ((int64_t)B * dim < (1 << 18)) { exact_norms_range(q, B, dim, out); return; }
+    const int32_t groups = (B + 7) / 8;                 // groups of eight queries, shared out over the pool
+    HostPool::get().run(groups, [&](int g) {
+        const int32_t b0 = g * 8, nb = std::min<int32_t>(8, B - b0);
+        exact_norms_range(q + (size_t)b0 * dim, nb, dim, out + b0);
+    });
+}
+
+void exact_norms_range(const float *q, int32_t B, int32_t dim, double *out)
 {
     int32_t b = 0;
     for (; b + 8 <= B; b += 8) {
@@ -465,6 +538,7 @@ void orr_index_destroy(orr_index *idx)
     }
     idx->d_dead.release();
     if (!idx->is_view) { idx->vlong_start.release(); idx->vlong_len.release(); idx->vlong_id.release(); }
+    idx->ws_norm_a.release();
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
@@ -472,7 +546,7 @@ void orr_index_destroy(orr_index *idx)
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
     idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
-    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release();
+    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release(); idx->pin_norm.release();
     if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
@@ -1168,6 +1242,31 @@ static int32_t sample_segments(int32_t n_seg_all, int64_t n, int32_t k, bool sma
     return (int32_t)std::min<int64_t>(64, std::max<int64_t>(small_batch ? 2 : 4, segs));
 }
 
+// ORR_HOST_TIMING=1: where the host side of a search spends its time, printed to stderr every 64 calls (diagnostic,
+// one searching thread).
+struct HostTiming {
+    bool on = getenv("ORR_HOST_TIMING") != nullptr;
+    double acc[8] = {0};
+    int64_t calls = 0;
+    std::chrono::steady_clock::time_point last;
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void mark(int i)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+    }
+    void done()
+    {
+        if (!on || ++calls % 64 != 0) return;
+        fprintf(stderr, "[orr host ms/call] query_setup+cos_launch %.3f | keyword_prep+launch %.3f | norms+consts %.3f | select_launches %.3f | "
+                        "wait_gpu %.3f | finish %.3f\n", acc[0] / 64, acc[1] / 64, acc[2] / 64, acc[3] / 64, acc[4] / 64, acc[5] / 64);
+        for (double &x : acc) x = 0;
+    }
+};
+HostTiming g_ht;
+
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
@@ -1175,6 +1274,7 @@ static int32_t sample_segments(int32_t n_seg_all, int64_t n, int32_t k, bool sma
 int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
               const orr_candidate **recs_host)
 {
+    g_ht.start();
     ORR_TRY(bind_device(idx));
     const int64_t n = participating_rows(idx, a.candidate_limit);
     const int32_t B = a.B;
@@ -1227,21 +1327,35 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     // ---- query vectors: the dot kernel reads them where they are (device) or from one upload
     const float *d_q = nullptr;
     bool q_download_pending = false;
+    // Queries that already live on the device get their exact norms there (the kernel that computes the rows' norms):
+    // no download of the vectors, no host pass over them.  The generic large-k path scores with host-side constants.
+    bool dev_norms = false;
+    idx->h_norm_a.assign((size_t)B, 0.0);
     if (use_cos) {
         const size_t qbytes = sizeof(float) * (size_t)B * a.dim;
-        ORR_TRY(idx->pin_q.reserve(qbytes));
-        if (is_device_pointer(a.q)) {
+        static const int dev_norm_min = [] { const char *e = getenv("ORR_DEV_NORMS_MIN_BATCH"); return e ? atoi(e) : 16; }();
+        if (is_device_pointer(a.q) && kprime <= orr::kSelWidth && B >= dev_norm_min) {
+            // (a handful of queries: the download and the host's pass cost less than the kernel's 3072-step chains)
+            d_q = a.q;
+            dev_norms = true;
+            ORR_TRY(idx->ws_norm_a.reserve(sizeof(double) * (size_t)B));
+            ORR_TRY(idx->pin_norm.reserve(sizeof(double) * (size_t)B));
+            HIP_TRY(orr::launch_dot_exact(d_q, B, a.dim, nullptr, 1, true, idx->ws_norm_a.as<double>(), B, idx->stream_kw));   // beside the first cosine kernel
+            HIP_TRY(hipEventRecord(idx->ev_q, idx->stream_kw));
+        } else if (is_device_pointer(a.q)) {
+            ORR_TRY(idx->pin_q.reserve(qbytes));
             d_q = a.q;
             HIP_TRY(hipMemcpyAsync(idx->pin_q.p, a.q, qbytes, hipMemcpyDeviceToHost, idx->stream_kw));
             HIP_TRY(hipEventRecord(idx->ev_q, idx->stream_kw));
             q_download_pending = true;
         } else {
+            ORR_TRY(idx->pin_q.reserve(qbytes));
             memcpy(idx->pin_q.p, a.q, qbytes);
             ORR_TRY(idx->ws_q.reserve(qbytes));
             HIP_TRY(hipMemcpyAsync(idx->ws_q.p, idx->pin_q.p, qbytes, hipMemcpyHostToDevice, s));
             d_q = idx->ws_q.as<float>();
         }
-        if (q_host) *q_host = idx->pin_q.as<float>();
+        if (q_host && !dev_norms) *q_host = idx->pin_q.as<float>();
     }
 
     if (n == 0) {   // nothing on this shard takes part: empty records + trailers
@@ -1255,7 +1369,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         if (direct_host) memcpy(d_cand, empty.data(), rec_bytes);
         else HIP_TRY(hipMemcpyAsync(d_cand, empty.data(), rec_bytes, hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
+        if (q_download_pending || dev_norms) HIP_TRY(hipEventSynchronize(idx->ev_q));    // nothing reads the caller's vectors after the call
         if (recs_host && direct_host) *recs_host = d_cand;
         return ORR_OK;
     }
@@ -1352,6 +1466,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         }
     }
 
+    g_ht.mark(0);
     // ---- K3 keyword side on its own stream: distinct terms -> vocabulary scan -> posting lists
     // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
     orr::KwView kw{nullptr, 0, nullptr, nullptr};
@@ -1463,26 +1578,31 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         kw_max_hits = max_hits;
     }
 
+    g_ht.mark(1);
     // ---- per-query constants (exact normA needs the vectors on the host)
     const bool batched_score = (B >= 4 || ts_stream) && kprime <= orr::kSelWidth;     // per-row pieces once per batch
     if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
     ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     orr::QueryConst *qc = idx->pin_qc.as<orr::QueryConst>();
-    idx->h_norm_a.assign((size_t)B, 0.0);
-    if (use_cos) exact_norms(idx->pin_q.as<float>(), B, a.dim, idx->h_norm_a.data());
+    if (use_cos && !dev_norms) exact_norms(idx->pin_q.as<float>(), B, a.dim, idx->h_norm_a.data());
     for (int32_t b = 0; b < B; ++b) {
         qc[b].use_cos = use_cos ? 1 : 0;
         qc[b].norm_a = idx->h_norm_a[(size_t)b];
         qc[b].n_terms = (int32_t)(qoff[b + 1] - qoff[b]);
         qc[b].inv_n_terms = qc[b].n_terms > 0 ? 1.0 / (double)qc[b].n_terms : 0.0;
         qc[b].inv_sqrt_na = 0.0;
-        if (batched_score && use_cos) {
+        if (batched_score && use_cos && !dev_norms) {
             if (qc[b].norm_a <= 0.0) qc[b].use_cos = 0;                    // guard :84 -> cosine 0 for every row
             else qc[b].inv_sqrt_na = 1.0 / std::sqrt(qc[b].norm_a);        // NaN stays NaN
         }
     }
     HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
+    if (dev_norms) {
+        HIP_TRY(hipStreamWaitEvent(s, idx->ev_q, 0));
+        HIP_TRY(orr::launch_patch_query_norms(idx->ws_qc.as<orr::QueryConst>(), idx->ws_norm_a.as<double>(), B, batched_score, s));
+        HIP_TRY(hipMemcpyAsync(idx->pin_norm.p, idx->ws_norm_a.p, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, s));
+    }
     // per-row selection constants do not depend on the keyword side: enqueued before the main stream waits for it
     const double2 *d_rowc_early = nullptr;
     if (batched_score && kprime <= orr::kSelWidth) {
@@ -1492,6 +1612,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         d_rowc_early = idx->ws_rowc.as<double2>();
     }
     if (n_terms_total > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_kw_done, 0));
+    g_ht.mark(2);
 
     // ---- K4/K5 fused score + selection
     if (kprime <= orr::kSelWidth) {
@@ -1740,7 +1861,14 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (!owner_of(idx)->dead.empty())      // records of deleted rows are dropped by the host finish
         HIP_TRY(orr::launch_mark_dead_records(d_cand, B, kprime, owner_of(idx)->d_dead.as<int64_t>(),
                                               (int32_t)owner_of(idx)->dead.size(), idx->row_base, s));
+    if (host_records && !direct_host) {     // large record sets: one asynchronous copy into pinned memory behind the last kernel
+        ORR_TRY(idx->pin_cand.reserve(rec_bytes));
+        HIP_TRY(hipMemcpyAsync(idx->pin_cand.p, d_cand, rec_bytes, hipMemcpyDeviceToHost, s));
+    }
+    g_ht.mark(3);
     HIP_TRY(hipStreamSynchronize(s));
+    if (dev_norms) memcpy(idx->h_norm_a.data(), idx->pin_norm.p, sizeof(double) * (size_t)B);
+    g_ht.mark(4);
     collect_events(idx);
     if (kw_overflow_possible) {
         unsigned long long cnt = 0;
@@ -1750,6 +1878,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                         (uint32_t)(cnt >> 32), kw_max_hits);
     }
     if (recs_host && direct_host) *recs_host = d_cand;
+    else if (recs_host && host_records) *recs_host = idx->pin_cand.as<orr_candidate>();
     return ORR_OK;
 }
 
@@ -1851,22 +1980,20 @@ int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate 
         }
     };
     const int64_t n_records = (int64_t)B * n_shards * kprime;
-    int n_thr = n_records >= 16384 ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-    if (n_thr > B) n_thr = B;
+    int n_thr = n_records >= 4096 ? std::min(HostPool::get().width() * 2, (B + 15) / 16) : 1;     // tasks of >= 16 queries
+    if (n_thr < 1) n_thr = 1;
     std::vector<int32_t> t_unc((size_t)n_thr, 0);
     std::vector<int> t_err((size_t)n_thr, ORR_OK);
     if (n_thr == 1) {
         work(0, B, &t_unc[0], &t_err[0]);
     } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < n_thr; ++t)
-            th.emplace_back(work, (int32_t)((int64_t)B * t / n_thr), (int32_t)((int64_t)B * (t + 1) / n_thr), &t_unc[(size_t)t], &t_err[(size_t)t]);
-        work(0, (int32_t)((int64_t)B / n_thr), &t_unc[0], &t_err[0]);
-        for (auto &x : th) x.join();
+        HostPool::get().run(n_thr, [&](int t) {
+            work((int32_t)((int64_t)B * t / n_thr), (int32_t)((int64_t)B * (t + 1) / n_thr), &t_unc[(size_t)t], &t_err[(size_t)t]);
+        });
     }
     for (int t = 0; t < n_thr; ++t) {
         if (t_err[(size_t)t] != ORR_OK)
-            return t == 0 ? t_err[0] : fail(t_err[(size_t)t], "orr_merge_candidates: a shard's records are malformed");
+            return n_thr == 1 ? t_err[0] : fail(t_err[(size_t)t], "orr_merge_candidates: a shard's records are malformed");   // the detail was set on a pool thread
         unc += t_unc[(size_t)t];
     }
     if (out_uncertified) *out_uncertified = unc;
@@ -1933,6 +2060,8 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
         int32_t unc = 0;
         ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, use_cos ? idx->h_norm_a.data() : nullptr,
                            query_term_off, now_ticks, topk, out_rows, out_scores, out_counts, &unc));
+        g_ht.mark(5);
+        g_ht.done();
         if (unc == 0) return ORR_OK;
         if (a.used_fused && !a.no_fuse) { a.no_fuse = true; continue; }   // a buffer overflow or a tie at the cut: unfused pass
         if (a.used_mfma) { a.force_exact = true; continue; }        // then the exact pass, same k'

@@ -104,6 +104,9 @@ struct QueryConst {
     int32_t use_cos;      // query dim == index dim, dim > 0 (and norm_a > 0 in the batched form)
 };
 
+// qc[b].norm_a / inv_sqrt_na / use_cos from norms computed on the device (launch_dot_exact, self_norm over the queries).
+hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s);
+
 // Per-row selection constants for a batch: out[r] = {1/sqrt(normB) or 0, recency * 0.1}.
 hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64_t now_ticks, int64_t n_rows,
                              double2 *out, hipStream_t s);

@@ -35,6 +35,27 @@ __global__ __launch_bounds__(256) void row_consts_kernel(const double *__restric
     }
 }
 
+// Query norms computed on the device (queries that already live there): fills the norm-dependent fields of the
+// per-query constants exactly as the host does for host-resident queries.
+__global__ void patch_query_norms_kernel(QueryConst *__restrict__ qc, const double *__restrict__ norm_a, int32_t B, int32_t batched)
+{
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double na = norm_a[b];
+    qc[b].norm_a = na;
+    if (batched && qc[b].use_cos) {
+        if (na <= 0.0) qc[b].use_cos = 0;                 // guard :84 -> cosine 0 for every row
+        else qc[b].inv_sqrt_na = 1.0 / sqrt(na);          // NaN stays NaN
+    }
+}
+
+hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(patch_query_norms_kernel, dim3((B + 255) / 256), dim3(256), 0, s, qc, norm_a, B, batched ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64_t now_ticks, int64_t n_rows,
                              double2 *out, hipStream_t s)
 {
