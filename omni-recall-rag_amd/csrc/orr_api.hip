@@ -1306,9 +1306,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth &&
         B <= orr::kMaxGemvScreenQ) {
         ORR_TRY(ensure_i8_shadow(idx));
-        ts_i8 = idx->i8_ready;                           // 5..8 queries: two launches of the int8 stream
+        ts_i8 = idx->i8_ready;
         if (!ts_i8) ORR_TRY(ensure_shadow(idx));
         ts_stream = ts_i8 || idx->shadow_ready;
+        // 5..8 queries on the int8 shadow: the screening GEMM with one live query tile is HBM-bound as well and
+        // reads the rows once, the stream would need two launches (1M x 3072: 8 queries 1.39 -> 0.97 ms)
+        static const int i8_stream_max = [] { const char *e = getenv("ORR_I8_STREAM_MAX"); return e ? atoi(e) : orr::kMaxI8ScreenQ; }();
+        if (ts_i8 && B > i8_stream_max) { ts_i8 = false; ts_stream = false; }
     }
     const bool use_mfma = use_cos && !a.force_exact && (B >= mfma_min_batch || ts_stream) && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
     const bool approx_pass = use_mfma;                   // records carry no dot yet: filled in exactly on the device

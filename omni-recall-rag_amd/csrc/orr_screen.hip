@@ -62,7 +62,12 @@ typedef int i32x16v __attribute__((ext_vector_type(16)));
 // I8 = true (K2j): the same kernel on the int8 shadow and int8 queries -- an image row's 64 bytes are 64 k,
 // v_mfma_i32_32x32x32_i8 consumes the same 16-byte fragments at twice the rate, the accumulator is the exact
 // integer dot, half as many K-tiles and half the bytes per row.
-template <bool FUSED, int MODE, bool I8>
+//
+// LIVE = 32-query tiles of the 256-query tile that hold queries (8: all).  Batches of at most 128 queries only
+// fill the first LIVE <= 4 of them: waves 4..7 (query rows 128..255) then only keep requesting row pieces,
+// waves 0..3 multiply their first LIVE query tiles, the upper half of the query image is never requested
+// (LIVE <= 2: nor its second quarter) -- the kernel turns from latency- into HBM-bound.
+template <bool FUSED, int MODE, bool I8, int LIVE = 8>
 __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
                                                              const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
                                                              int32_t D, float *__restrict__ S, int64_t s_stride,
@@ -72,6 +77,9 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    constexpr int LI = LIVE >= 4 ? 4 : LIVE;                               // query tiles a multiplying wave owns
+    const bool active = LIVE == 8 || wr == 0;
+    constexpr int kPiecesActive = LIVE == 8 ? 4 : 3, kPiecesIdle = LIVE <= 2 ? 2 : 3;
     // ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
     const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
     const int mt = slot_id % n_mtiles, nt = (slot_id / n_mtiles) * 8 + xcd;
@@ -89,6 +97,8 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         const int tc = t < T ? t : T - 1;                                   // past the end: a spare copy of the last tile
         unsigned char *base = lds + (t % kScNS) * kScStage + wave * 1024 + (g & 1) * 8192 + (g >> 1) * kScImage;
         if (MODE == 2 || (MODE == 4 && g < 2) || (MODE == 5 && g >= 2)) return;
+        if (LIVE < 8 && g == 1) return;                                     // query rows 128..255: padding nobody reads
+        if (LIVE <= 2 && g == 0 && wr != 0) return;                         // query rows 64..127 likewise (KiB 4..7 of the piece)
         // rows are streamed once when the whole batch fits one query tile: non-temporal, so they do not push
         // the query images (re-read by every workgroup) out of L2
         if (g < 2) glds16<0>(a_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
@@ -96,9 +106,9 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         else glds16<0>(b_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
     };
 
-    typename std::conditional<I8, i32x16v, f32x16>::type acc[4][2];
+    typename std::conditional<I8, i32x16v, f32x16>::type acc[LI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < LI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -109,19 +119,20 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     const int s0 = fh ^ ((fr >> 2) & 3);                                    // slot of ks = 0; ks = 1 flips bit 1
     const int a_row = (wr * 128 + fr) * 64, b_row = kScImage + (wc * 64 + fr) * 64;
 
-    struct Frag { bf16x8 a[4], b[2]; };
+    struct Frag { bf16x8 a[LI], b[2]; };
     auto read_frag = [&](Frag &f, int t, int ks) {
         const unsigned char *st = lds + (t % kScNS) * kScStage;
         const int so = ((2 * ks) ^ s0) * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 2048 + so);
+        for (int i = 0; i < LI; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 2048 + so);
 #pragma unroll
         for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_row + j * 2048 + so);
     };
 
 #define ORR_SB __builtin_amdgcn_sched_barrier(0)
 #define ORR_MM(f, i) \
-    if constexpr (I8) { \
+    if constexpr ((i) >= LI) { \
+    } else if constexpr (I8) { \
     acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[0]), acc[i][0], 0, 0, 0); \
     acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[1]), acc[i][1], 0, 0, 0); \
     } else if constexpr (MODE != 1 && MODE != 4 && MODE != 5) { \
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     // s_setprio(1) around every MFMA pair: no gain; a fourth tile in flight instead of the early fragment
     // reads of tile t+1: 12 % slower; not requesting query pieces past the batch: no change.)
 #define ORR_TILE(CUR0, CUR1, NXT0, NXT1, t) \
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (kScNS - 3)) : "memory"); \
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesActive * (kScNS - 3)) : "memory"); \
     issue_piece((t) + kScNS - 1, 0); ORR_SB; \
     ORR_MM(CUR0, 0); \
     read_frag(NXT0, (t) + 1, 0); ORR_SB; \
@@ -156,13 +167,24 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     for (int t = 0; t < kScNS - 1; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue_piece(t, g);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(4 * (kScNS - 2)) : "memory");
-    Frag fa0, fa1, fb0, fb1;
-    read_frag(fa0, 0, 0);
-    read_frag(fa1, 0, 1);
-    for (int t = 0; t < T; t += 2) {                                        // T = D / 32 is even
-        ORR_TILE(fa0, fa1, fb0, fb1, t);
-        ORR_TILE(fb0, fb1, fa0, fa1, t + 1);
+    if (active) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesActive * (kScNS - 2)) : "memory");
+        Frag fa0, fa1, fb0, fb1;
+        read_frag(fa0, 0, 0);
+        read_frag(fa1, 0, 1);
+        for (int t = 0; t < T; t += 2) {                                    // T = D / 32 is even
+            ORR_TILE(fa0, fa1, fb0, fb1, t);
+            ORR_TILE(fb0, fb1, fa0, fa1, t + 1);
+        }
+    } else {
+        // waves without queries: the same barriers, their share of the row (and query) pieces, nothing else
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesIdle * (kScNS - 2)) : "memory");
+        for (int t = 0; t < T; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesIdle * (kScNS - 3)) : "memory");
+            issue_piece(t + kScNS - 1, 0);
+            issue_piece(t + kScNS - 1, 2);
+            issue_piece(t + kScNS - 1, 3);
+        }
     }
 #undef ORR_TILE
 #undef ORR_MM
@@ -170,8 +192,9 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the spare pieces of the last tiles
 
     if (!FUSED) {
+        if (active)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < LI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int64_t col = n0 + wc * 64 + j * 32 + fr;
@@ -183,17 +206,18 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
             }
     } else {
         __syncthreads();                                                    // every wave is done with the operand images
+        if (!active) return;
         if constexpr (I8) {
-            f32x16 accf[4][2];                                              // |I| <= 3072 * 127^2: the conversion costs at most 2^-24
+            f32x16 accf[LI][2];                                             // |I| <= 3072 * 127^2: the conversion costs at most 2^-24
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < LI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) accf[i][j][e] = (float)acc[i][j][e];
-            fused_epilogue<4, 2, true>(accf, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+            fused_epilogue<LI, 2, true>(accf, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
         } else {
-            fused_epilogue<4, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+            fused_epilogue<LI, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
         }
     }
 }
@@ -617,12 +641,19 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kScLds);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true>), dim3((unsigned)blocks), dim3(512), kScLds, s,
-                       static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D,
-                       static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi);
+    static const int live_max = [] { const char *e = getenv("ORR_SCREEN_LIVE"); return e ? atoi(e) : 0; }();   // 8: always the full tile
+#define ORR_LAUNCH_I8(L) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, true, L>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true, L>), dim3((unsigned)blocks), dim3(512), kScLds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi); } while (0)
+    if (live_max == 8 || B > 128) ORR_LAUNCH_I8(8);
+    else if (B > 64) ORR_LAUNCH_I8(4);
+    else if (B > 32) ORR_LAUNCH_I8(2);
+    else ORR_LAUNCH_I8(1);
+#undef ORR_LAUNCH_I8
     return hipGetLastError();
 }
 
@@ -739,7 +770,19 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<F, M, false>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, E); } while (0)
-    if (epi) ORR_LAUNCH(true, 0, *epi);
+    static const int live_max = [] { const char *e = getenv("ORR_SCREEN_LIVE"); return e ? atoi(e) : 0; }();   // 8: always the full tile
+#define ORR_LAUNCH_LIVE(L) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, false, L>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, false, L>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
+                           S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, *epi); } while (0)
+    if (epi) {
+        if (live_max == 8 || B > 128) ORR_LAUNCH_LIVE(8);
+        else if (B > 64) ORR_LAUNCH_LIVE(4);
+        else if (B > 32) ORR_LAUNCH_LIVE(2);
+        else ORR_LAUNCH_LIVE(1);
+    }
     else if (mode == 1) ORR_LAUNCH(false, 1, none);
     else if (mode == 2) ORR_LAUNCH(false, 2, none);
     else if (mode == 3) ORR_LAUNCH(false, 3, none);
@@ -747,6 +790,7 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     else if (mode == 5) ORR_LAUNCH(false, 5, none);
     else ORR_LAUNCH(false, 0, none);
 #undef ORR_LAUNCH
+#undef ORR_LAUNCH_LIVE
     return hipGetLastError();
 }
 

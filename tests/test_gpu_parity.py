@@ -473,14 +473,14 @@ def test_two_stage_batched_pass_matches_oracle():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow), (topk, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (topk, b)
-    # 1..8 queries: exact (1..4) or f32-MFMA (5..8) dots over the prefix give the floor, the shadow is streamed
-    # without the matrix core
+    # 1..4 queries: the int8 shadow is streamed without the matrix core (the sample first, for the floor);
+    # 5..8 queries take the screening GEMM with one live query tile
     idx.set_option("two_stage", 1)
     for b0, nb in ((0, 1), (2, 1), (3, 1), (0, 4), (4, 3), (100, 2), (0, 8), (1, 6)):
         idx.set_profiling(True)
         rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
         st = idx.kernel_stats()
-        assert "screen_gemv_i8" in st, sorted(st)       # dim 128: the int8 shadow applies (two launches beyond 4 queries)
+        assert ("screen_gemv_i8" if nb <= 4 else "screen_i8_fused") in st, sorted(st)     # dim 128: the int8 shadow applies
         idx.set_profiling(False)
         for b in range(nb):
             orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
@@ -583,7 +583,7 @@ def test_int8_shadow_with_rows_and_queries_that_quantise_badly():
     corpus = orc.OracleCorpus(emb, created, contents)
     idx.set_profiling(True)
     r4, s4, c4 = idx.search(qs[:4], terms[:4], NOW, 10, candidate_limit=n)            # int8 stream
-    r7, s7, c7 = idx.search(qs[:7], terms[:7], NOW, 10, candidate_limit=n)            # two launches of it
+    r7, s7, c7 = idx.search(qs[:7], terms[:7], NOW, 10, candidate_limit=n)            # int8 GEMM, one live query tile
     rB, sB, cB = idx.search(qs, terms, NOW, 10, candidate_limit=n)                    # int8 GEMM
     stats = idx.kernel_stats()
     idx.set_profiling(False)
