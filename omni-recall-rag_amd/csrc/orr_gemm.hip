@@ -698,6 +698,88 @@ hipError_t launch_records_dot_from_buffer(const SelEntry *buf, const double *buf
     return hipGetLastError();
 }
 
+// The same for small batches, where this kernel's latency is on the critical path of the call: FOUR lanes per
+// survivor.  The sum's order is fixed (3072 dependent fp64 additions), but the row's bytes need not arrive in
+// that rhythm, and the products (fp32 multiply, widen) are not part of the chain: lane c of a quad holds columns
+// [256 r + 64 c, +64) of round r and forms its 64 products while the other three do the same; then the four
+// lanes add theirs one after the other -- 64 dependent v_add_f64 each, nothing else in the chain -- the running
+// sum handed on by a quad broadcast (DPP).  16 survivors per wave.  D % 256 == 0.
+template <int S>
+__device__ __forceinline__ double quad_broadcast(double v)
+{
+    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);              // quad_perm [S,S,S,S]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int S>
+__device__ __forceinline__ double quad_step(double acc, const double (&prod)[64], int c)
+{
+    if (c == S) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc += prod[i];                       // the reference's order: 64 dependent additions
+    }
+    return quad_broadcast<S>(acc);
+}
+
+__global__ __launch_bounds__(64) void rescore_buffer_exact_quad_kernel(const float *__restrict__ E, int32_t D,
+                                                                       const float *__restrict__ Q,
+                                                                       const double *__restrict__ norm_b,
+                                                                       const int64_t *__restrict__ created, KwView kw,
+                                                                       const QueryConst *__restrict__ qcs, int64_t now_ticks,
+                                                                       const uint32_t *__restrict__ cnt, uint32_t cap,
+                                                                       SelEntry *__restrict__ buf, double *__restrict__ buf_dot)
+{
+    const int lane = threadIdx.x, b = blockIdx.x, c = lane & 3, r16 = lane >> 2;
+    const uint32_t n = cnt[b] < cap ? cnt[b] : cap;
+    const uint32_t first = blockIdx.y * 16u;
+    if (first >= n) return;
+    SelEntry *mine = buf + (int64_t)b * cap + first;
+    const bool live = first + r16 < n;
+    const int64_t my_row = live ? (int64_t)mine[r16].pos : 0;             // quads without a survivor read row 0 and are ignored
+    const float *src = E + my_row * (int64_t)D + c * 64;
+    const float *qsrc = Q + (int64_t)b * D + c * 64;
+    float4 cur[16], qc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        cur[j] = *reinterpret_cast<const float4 *>(src + j * 4);
+        qc[j] = *reinterpret_cast<const float4 *>(qsrc + j * 4);
+    }
+    double acc = 0.0;
+    for (int c0 = 0; c0 < D; c0 += 256) {
+        // the products are not part of the chain: all four lanes of the quad round and widen theirs at once
+        double prod[64];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float p0 = qc[j].x * cur[j].x;
+            float p1 = qc[j].y * cur[j].y;
+            float p2 = qc[j].z * cur[j].z;
+            float p3 = qc[j].w * cur[j].w;
+            prod[4 * j + 0] = (double)p0; prod[4 * j + 1] = (double)p1; prod[4 * j + 2] = (double)p2; prod[4 * j + 3] = (double)p3;
+        }
+        const int cn = c0 + 256 < D ? c0 + 256 : c0;                      // clamped, never branched around
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            cur[j] = *reinterpret_cast<const float4 *>(src + cn + j * 4);
+            qc[j] = *reinterpret_cast<const float4 *>(qsrc + cn + j * 4);
+        }
+        acc = quad_step<0>(acc, prod, c);
+        acc = quad_step<1>(acc, prod, c);
+        acc = quad_step<2>(acc, prod, c);
+        acc = quad_step<3>(acc, prod, c);
+    }
+    if (live && c == 0) {
+        const QueryConst qc0 = qcs[b];
+        const uint32_t m = qc0.n_terms > 0 ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
+        QueryConst exact = qc0;
+        exact.use_cos = 1;
+        mine[r16].key = score_key(fused_score(acc, norm_b[my_row], created[my_row], m, exact, now_ticks));
+        buf_dot[(int64_t)b * cap + first + r16] = acc;
+    }
+}
+
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
                                        const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
                                        const uint32_t *cnt, uint32_t cap, SelEntry *buf, double *buf_dot, hipStream_t s)
@@ -705,7 +787,11 @@ hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q
     if (B <= 0) return hipSuccess;
     if (D % 64 != 0) return hipErrorInvalidValue;
     static const bool via_lds = [] { const char *e = getenv("ORR_RESCORE_LDS"); return e && atoi(e) != 0; }();
-    if (via_lds)
+    static const int quad_max = [] { const char *e = getenv("ORR_RESCORE_QUAD_MAX_BATCH"); return e ? atoi(e) : 64; }();
+    if (D % 256 == 0 && B <= quad_max && !via_lds)
+        hipLaunchKernelGGL(rescore_buffer_exact_quad_kernel, dim3((unsigned)B, cap / 16), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
+                           now_ticks, cnt, cap, buf, buf_dot);
+    else if (via_lds)
         hipLaunchKernelGGL(rescore_buffer_exact_kernel<true>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
                            now_ticks, cnt, cap, buf, buf_dot);
     else

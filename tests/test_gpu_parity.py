@@ -598,6 +598,40 @@ def test_int8_shadow_with_rows_and_queries_that_quantise_badly():
     idx.close()
 
 
+def test_two_stage_pass_at_a_dimension_that_is_a_multiple_of_256():
+    """dim % 256 == 0 lets small batches re-score their survivors four lanes per row (the sum's order stays
+    the reference's; only the loads are spread); checked against the oracle directly."""
+    P = pkg()
+    rng = np.random.default_rng(81)
+    n, dim = 200_000, 256
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    emb[:64] *= np.float32(1e3)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm"])
+    contents = [" ".join(w) for w in words[rng.integers(0, len(words), (n, 4))]]
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], [c.encode() for c in contents[r0:r0 + 50_000]])
+    idx.seal()
+    B = 70
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[0] = emb[n - 3]
+    qs[1] = emb[10] * np.float32(0.5)
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    corpus = orc.OracleCorpus(emb, created, contents)
+    for b0, nb in ((0, 1), (0, 4), (1, 7), (0, 17), (0, 64), (0, 70)):     # 70: the one-row-per-lane form again
+        idx.set_profiling(True)
+        rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
+        st = idx.kernel_stats()
+        idx.set_profiling(False)
+        assert "rescore_buffer_exact" in st and "dot_exact" not in st, sorted(st)
+        for b in sorted({0, min(1, nb - 1), nb - 1}):
+            orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
+            assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (b0, nb, b)
+    idx.close()
+
+
 def test_empty_and_degenerate_inputs():
     """Empty corpus, rows with empty content, queries without terms or vectors, API misuse."""
     P = pkg()
