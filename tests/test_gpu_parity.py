@@ -629,6 +629,47 @@ def test_two_stage_pass_at_a_dimension_that_is_a_multiple_of_256():
         for b in sorted({0, min(1, nb - 1), nb - 1}):
             orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (b0, nb, b)
+    import torch
+    qd = torch.from_numpy(qs).to("cuda:0")                                 # device-resident batch: norms computed on the device
+    for nb in (70, 20, 3):
+        h = idx.search(qs[:nb], terms[:nb], NOW, 10, candidate_limit=n)
+        d = idx.search(qd[:nb], terms[:nb], NOW, 10, candidate_limit=n)
+        assert all(np.array_equal(x, y) for x, y in zip(h, d)), nb
+    idx.close()
+
+
+@pytest.mark.parametrize("n,dim", [(3000, 3), (5000, 64), (4000, 256)])
+def test_device_resident_query_batches_get_the_same_norms_as_host_ones(n, dim):
+    """Batches of 16+ queries that already live on the device have their exact norms computed there (the kernel
+    that computes the rows' norms); host-resident queries get them on the host.  Same queries, both ways, plus
+    the oracle: zero, tiny, huge, NaN and duplicate queries included."""
+    import torch
+    P = pkg()
+    rng = np.random.default_rng(82 + dim)
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    B = 40
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[1] = 0.0
+    qs[2] *= np.float32(1e-20)
+    qs[3] *= np.float32(1e18)
+    qs[4, 0] = np.nan
+    qs[5] = qs[6]
+    qs[7] = next(e for e in c["emb"] if e is not None)
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    host = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    qd = torch.from_numpy(qs).to("cuda:0")
+    for nb in (B, 16, 15):
+        dev = idx.search(qd[:nb], terms[:nb], NOW, 10, candidate_limit=n)
+        for x, y in zip(host, dev):
+            assert np.array_equal(x[:nb], y, equal_nan=True), nb
+    for b in range(9):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n)
+        assert list(host[0][b, :host[2][b]]) == list(orow), b
+        a = host[1][b, :host[2][b]]
+        assert ((a == osc) | (np.isnan(a) & np.isnan(osc))).all(), b
     idx.close()
 
 
