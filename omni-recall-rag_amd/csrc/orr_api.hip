@@ -1387,6 +1387,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     bool two_stage = false;            // plain-bf16 first stage over all rows + exact second stage
     bool records_have_dots = false;    // two-stage: exact dots copied from the survivors' buffer
     bool ts_gemv = false;              // two-stage with the streaming screen (1..8 queries)
+    bool prefix_i8 = false;            // the sampled prefix went through the int8 screening GEMM: its keys are lower bounds
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
         if (!ts_stream && (B <= 64 || getenv("ORR_GEMM_KIND"))) {
@@ -1439,9 +1440,30 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
                 ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
                 d_dotf = idx->ws_dotf.as<float>();
-                Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
-                HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, dotf_rows, idx->dim, d_dotf, dotf_rows, nullptr, 3, s));
-                bf16_split = true;
+                // Where the int8 shadow exists the sampled prefix goes through the int8 screening GEMM as well (integer
+                // dots out; fuse_select turns them into LOWER bounds of the scores with the per-pair bound), which reads
+                // a quarter of the bytes of the split pass and runs at twice its MFMA rate.  ORR_I8_PREFIX=0: split pass.
+                static const bool i8_prefix_on = [] { const char *e = getenv("ORR_I8_PREFIX"); return !e || atoi(e) != 0; }();
+                if (two_stage && fused_sample_seg > 0 && idx->opt_two_stage == 1 && idx->dim % 128 == 0 && i8_prefix_on) {
+                    ORR_TRY(ensure_i8_shadow(idx));
+                    prefix_i8 = idx->i8_ready;
+                }
+                if (prefix_i8) {
+                    ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
+                    ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
+                    ORR_TRY(idx->ws_q8err.reserve(2 * sizeof(double) * (size_t)B));
+                    ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
+                    HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s,
+                                                   idx->ws_q8err.as<double>() + B));
+                    HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
+                    const int64_t pre_rows = std::min<int64_t>(dotf_rows, n);
+                    Timed t(idx, "screen_i8_prefix", 1.0 * (double)pre_rows * idx->dim + 1.0 * (double)B * idx->dim + 4.0 * (double)B * (double)pre_rows);
+                    HIP_TRY(orr::launch_screen_i8_dots(idx->ws_qtiled.p, B, idx->emb_i8.p, pre_rows, idx->dim, d_dotf, dotf_rows, s));
+                } else {
+                    Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
+                    HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, dotf_rows, idx->dim, d_dotf, dotf_rows, nullptr, 3, s));
+                    bf16_split = true;
+                }
             }
         }
         // Error of the approximate dot against the reference sum, relative to sum|q_k e_k| (<= |q||e| by
@@ -1458,7 +1480,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         approx_eps = 0.7 * 1.01 * eps_cos + 1e-12;
         // streaming form: the prefix is scored by the plain-bf16 stream itself, so its floor carries that bound
         if (ts_gemv) approx_eps = 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * u23) + 1e-12;
-        if (ts_i8) approx_eps = 1e-12;           // int8 form: the sample's keys are already lower bounds
+        if (ts_i8 || prefix_i8) approx_eps = 1e-12;    // int8 forms: the sample's keys are already lower bounds
     } else if (use_cos) {
         ORR_TRY(idx->ws_dot.reserve(sizeof(double) * (size_t)B * (size_t)n));
         d_dot = idx->ws_dot.as<double>();
@@ -1639,10 +1661,12 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             d_tau = idx->ws_tau.as<unsigned long long>();
             if (!ts_gemv) {
                 Timed t(idx, "fuse_select", (double)B * (double)dotf_rows * 28.0);
+                orr::I8Prefix i8p;
+                if (prefix_i8) { i8p.rowf = idx->i8_rowf.as<float4>(); i8p.qs1 = idx->ws_q8s1.as<float>(); i8p.qerr2 = idx->ws_q8err.as<double>() + B; }
                 HIP_TRY(orr::launch_fuse_select(nullptr, d_dotf, dotf_rows, idx->d_norm_b,
                                                 idx->d_created, d_rowc, kw, idx->ws_qc.as<orr::QueryConst>(), a.now_ticks,
-                                                dotf_rows, B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
-                                                lists_total, s));
+                                                std::min<int64_t>(dotf_rows, n), B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
+                                                lists_total, s, i8p));
             }
             ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * (size_t)B));
             orr::FusedEpilogue epi{};
@@ -1716,11 +1740,13 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                     if (!gemm_i8) ORR_TRY(ensure_shadow(idx));
                 }
                 if (gemm_i8) {
-                    ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
-                    ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
-                    ORR_TRY(idx->ws_q8err.reserve(2 * sizeof(double) * (size_t)B));
-                    HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s,
-                                                   idx->ws_q8err.as<double>() + B));
+                    if (!prefix_i8) {              // (the int8 prefix quantised and tiled the queries already)
+                        ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
+                        ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
+                        ORR_TRY(idx->ws_q8err.reserve(2 * sizeof(double) * (size_t)B));
+                        HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s,
+                                                       idx->ws_q8err.as<double>() + B));
+                    }
                     epi.i8_rowf = idx->i8_rowf.as<float4>();
                     epi.i8_qs1 = idx->ws_q8s1.as<float>();
                 }
@@ -1730,8 +1756,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                            gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (gemm_i8) {
-                    ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
-                    HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
+                    if (!prefix_i8) {
+                        ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
+                        HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
+                    }
                     Timed t(idx, "screen_i8_fused", 1.0 * (double)n * idx->dim + 1.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, n, idx->dim, epi, s));
                 } else if (ts_i8) {

@@ -118,11 +118,18 @@ hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64
 // row_consts != nullptr selects the batched (reciprocal-multiply) form of the score.
 // Scans segments [seg_first, seg_first+seg_count); tau != nullptr: per-query key a row must
 // exceed to be considered (the k'-th best key of an already scanned prefix).
+// i8.rowf != nullptr (with row_consts): dotf holds the INTEGER dots of the int8 screening GEMM over these rows
+// (launch_screen_i8_dots); the key is then a LOWER bound of the score: score(dot^) minus the per-pair bound.
+struct I8Prefix {
+    const float4 *rowf = nullptr;    // launch_i8_rowf
+    const float *qs1 = nullptr;      // [B] query scales
+    const double *qerr2 = nullptr;   // [B] |q - q^|^2 of the one-level queries
+};
 hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_stride, const double *norm_b,
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
-                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s);
+                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8 = I8Prefix());
 
 // K5b: merges the per-workgroup lists of each query and writes kprime candidate
 // records plus the trailer ([B][kprime+1], see orr_candidate).
@@ -192,6 +199,9 @@ hipError_t launch_i8_rowf(const float *scale, const float *rel_err, const float 
 hipError_t launch_i8_tile_queries(const void *q1_linear, int32_t B, int32_t D, void *tiled, hipStream_t s);
 hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D,
                             const FusedEpilogue &epi, hipStream_t s);
+// The same product over rows [0, n_rows) with the integer dots written out: S[b][r] = (float)I (the sampled prefix).
+hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, float *S,
+                                 int64_t s_stride, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
 hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
                                   unsigned long long *floor_key, double *L_out, hipStream_t s);

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
                                                            int64_t now_ticks, int64_t n_rows, int32_t seg_first,
                                                            int32_t n_seg_total,
                                                            const unsigned long long *__restrict__ tau,
-                                                           SelEntry *__restrict__ out_sel)
+                                                           SelEntry *__restrict__ out_sel, I8Prefix i8)
 {
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
@@ -579,6 +579,12 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
     const unsigned long long floor_key = tau ? tau[b] : 0ull;
     const int64_t seg0 = (int64_t)seg * kSelSegRows;
     const int64_t seg1 = (seg0 + kSelSegRows < n_rows) ? seg0 + kSelSegRows : n_rows;
+    // int8 prefix: the query's part of the per-pair bound, as the screening GEMM's epilogue forms it
+    double i8_qs1 = 0.0, i8_qw = 0.0;
+    if (FAST && i8.rowf) {
+        i8_qs1 = (double)i8.qs1[b];
+        i8_qw = qc.use_cos ? (double)__double2float_ru(0.7 * 1.000001 * sqrt(i8.qerr2[b]) * qc.inv_sqrt_na) : 0.0;
+    }
 
     // each of the 16 waves scores kSelSegRows/16 = 256 rows: 4 batches of 64 whose loads are
     // all issued before the first use
@@ -597,7 +603,14 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
                              : dotf  ? (double)dotf[(int64_t)b * dot_stride + r]     // K2 candidate pass
                                      : dot[(int64_t)b * dot_stride + r];             // K1e exact
             const uint32_t m = qc.n_terms > 0 ? kw_matches(kw, b, (uint32_t)r) : 0u;
-            if (FAST) {
+            if (FAST && i8.rowf) {
+                const double2 rc = row_consts[r];
+                const float4 rf = i8.rowf[r];
+                const double bound = qc.use_cos ? (double)rf.y + i8_qw * (double)rf.z : 0.0;
+                const double sc = fused_score_fast(d * ((double)rf.x * i8_qs1), rc.x, rc.y, m, qc) - bound;
+                nk[u] = score_key(sc);
+                if (!(fabs(sc) <= 1.7976931348623157e308)) nk[u] = 1ull;          // non-finite: no floor from it
+            } else if (FAST) {
                 const double2 rc = row_consts[r];
                 nk[u] = score_key(fused_score_fast(d, rc.x, rc.y, m, qc));
             } else {
@@ -642,17 +655,17 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
-                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s)
+                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8)
 {
     if (n_rows <= 0 || B <= 0 || seg_count <= 0) return hipSuccess;
     const int64_t n_seg = n_seg_stride > 0 ? n_seg_stride : (n_rows + kSelSegRows - 1) / kSelSegRows;
     if (n_seg > 65535) return hipErrorInvalidValue;
     if (row_consts)
         hipLaunchKernelGGL(fuse_select_kernel<true>, dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
-                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel);
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel, i8);
     else
         hipLaunchKernelGGL(fuse_select_kernel<false>, dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
-                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel);
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel, I8Prefix());
     return hipGetLastError();
 }
 

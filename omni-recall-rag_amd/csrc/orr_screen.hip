@@ -657,6 +657,31 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     return hipGetLastError();
 }
 
+hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, float *S,
+                                 int64_t s_stride, hipStream_t s)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (D <= 0 || D % 128 != 0 || !S) return hipErrorInvalidValue;
+    const int64_t n_ntiles = (n_rows + kScBN - 1) / kScBN;
+    const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
+    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const FusedEpilogue none{};
+#define ORR_LAUNCH_I8D(L) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<false, 0, true, L>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_bf16_kernel<false, 0, true, L>), dim3((unsigned)blocks), dim3(512), kScLds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           S, s_stride, (int32_t)n_ntiles, n_mtiles, 0, none); } while (0)
+    if (B > 128) ORR_LAUNCH_I8D(8);
+    else if (B > 64) ORR_LAUNCH_I8D(4);
+    else if (B > 32) ORR_LAUNCH_I8D(2);
+    else ORR_LAUNCH_I8D(1);
+#undef ORR_LAUNCH_I8D
+    return hipGetLastError();
+}
+
 size_t i8_tiled_bytes(int64_t n_rows, int32_t D)
 {
     return (size_t)((n_rows + kScBN - 1) / kScBN) * kScBN * (size_t)D;
