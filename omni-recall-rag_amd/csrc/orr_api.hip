@@ -1378,7 +1378,128 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         return ORR_OK;
     }
 
-    // ---- cosine numerators first: the long kernel starts before any other host work
+    // ---- K3 keyword side first, on its own stream (with the int8 prefix the main stream has little to do before it
+    // needs the bitmaps, so this chain is the critical path of a batch): distinct terms -> vocabulary scan -> posting lists
+    // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
+    orr::KwView kw{nullptr, 0, nullptr, nullptr};
+    bool kw_overflow_possible = false;
+    uint32_t kw_max_hits = 0;
+    if (n_terms_total > 0) {
+        // distinct terms of the batch: open addressing on an FNV-1a hash of the bytes (a batch of 1024 queries has
+        // ~3000 terms; the node-based map this replaces cost as much as the GPU side of a small batch)
+        std::vector<std::string_view> dterms;
+        dterms.reserve(n_terms_total);
+        uint32_t table_size = 16;
+        while (table_size < 2 * n_terms_total + 2) table_size <<= 1;
+        std::vector<uint32_t> table(table_size, 0xFFFFFFFFu);
+        std::vector<uint32_t> qmeta((size_t)n_terms_total + (size_t)B + 1);   // [term -> distinct idx][query offsets]
+        for (uint32_t t = 0; t < n_terms_total; ++t) {
+            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
+            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
+            std::string_view sv(reinterpret_cast<const char *>(a.terms_utf8) + o, e - o);
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char ch : sv) h = (h ^ ch) * 1099511628211ull;
+            uint32_t slot = (uint32_t)(h ^ (h >> 32)) & (table_size - 1);
+            while (table[slot] != 0xFFFFFFFFu && dterms[table[slot]] != sv) slot = (slot + 1) & (table_size - 1);
+            if (table[slot] == 0xFFFFFFFFu) {
+                table[slot] = (uint32_t)dterms.size();
+                dterms.push_back(sv);
+            }
+            qmeta[t] = table[slot];
+        }
+        for (int32_t b = 0; b <= B; ++b) qmeta[n_terms_total + b] = qoff[b] - t_begin;
+        const uint32_t TT = (uint32_t)dterms.size();
+        size_t pool_bytes = 0;
+        for (auto &d : dterms) pool_bytes += d.size();
+        // one pinned block, one upload: [ScanTerm x TT][qmeta][iota 0..64][term bytes]
+        const size_t off_terms = 0;
+        const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
+        const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
+        const size_t off_match = off_iota + sizeof(uint32_t) * 65;
+        const size_t off_pool = off_match + sizeof(orr::MatchTerm) * TT;
+        const size_t meta_bytes = off_pool + pool_bytes + 16;
+        ORR_TRY(idx->pin_meta.reserve(meta_bytes));
+        ORR_TRY(idx->ws_meta.reserve(meta_bytes));
+        uint8_t *hm = idx->pin_meta.as<uint8_t>();
+        orr::ScanTerm *st = reinterpret_cast<orr::ScanTerm *>(hm + off_terms);
+        uint32_t cursor = 0;
+        for (uint32_t t = 0; t < TT; ++t) {
+            st[t].off = cursor;
+            st[t].len = (uint32_t)dterms[t].size();
+            uint32_t pre = 0, msk = 0;
+            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
+                pre |= (uint32_t)(uint8_t)dterms[t][k] << (8 * k);
+                msk |= 0xFFu << (8 * k);
+            }
+            st[t].prefix = pre;
+            st[t].mask = msk;
+            orr::MatchTerm &mt = reinterpret_cast<orr::MatchTerm *>(hm + off_match)[t];
+            memset(&mt, 0, sizeof(mt));
+            mt.len = st[t].len;
+            for (uint32_t k = 0; k < 16 && k < st[t].len; ++k) {
+                mt.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
+                mt.m[k >> 2] |= 0xFFu << (8 * (k & 3));
+            }
+            memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
+            cursor += st[t].len;
+        }
+        memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
+        uint32_t *iota = reinterpret_cast<uint32_t *>(hm + off_iota);
+        for (uint32_t i = 0; i < 65; ++i) iota[i] = i;
+
+        const int64_t V = idx->n_tokens;
+        const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
+        const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
+        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, 16u << 20);
+        ORR_TRY(ensure_vlong(idx));
+        const int64_t VL = idx->n_vlong;
+        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
+        ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
+        ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
+        ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
+        hipStream_t k = idx->stream_kw;
+        uint8_t *dm = idx->ws_meta.as<uint8_t>();
+        HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
+        HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, sizeof(uint32_t) * (size_t)TT * (size_t)words, k));
+        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
+        if (V > 0) {
+            const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
+            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
+                Timed t(idx, "vocab_match", 0.0, k);
+                HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
+                                                      reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
+                                                      idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+            }
+            if (VL > 0) {   // longer tokens: every distinct term is its own 1-term "query" of the wave-per-token scan
+                {
+                    Timed t(idx, "vocab_scan", 0.0, k);
+                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(), VL,
+                                                   dm + off_pool, d_terms, (int32_t)TT, reinterpret_cast<const uint32_t *>(dm + off_iota),
+                                                   idx->ws_vmatch.as<uint16_t>(), k));
+                }
+                {
+                    Timed t(idx, "vocab_hits", 0.0, k);
+                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VL, (int32_t)TT, idx->vlong_id.as<uint32_t>(), idx->d_post_off,
+                                                   idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+                }
+            }
+            {
+                Timed t(idx, "expand_hits", 0.0, k);
+                HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
+                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k));
+            }
+        }
+        HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
+        kw.bitmaps = idx->ws_bitmaps.as<uint32_t>();
+        kw.words_per_term = words;
+        kw.q_term_idx = reinterpret_cast<const uint32_t *>(dm + off_qmeta);
+        kw.q_term_off = kw.q_term_idx + n_terms_total;
+        kw_overflow_possible = want_hits > (uint64_t)max_hits;
+        kw_max_hits = max_hits;
+    }
+
+    g_ht.mark(1);
+    // ---- cosine numerators
     double *d_dot = nullptr;
     float *d_dotf = nullptr;
     double approx_eps = 0.0;
@@ -1493,118 +1614,6 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     }
 
     g_ht.mark(0);
-    // ---- K3 keyword side on its own stream: distinct terms -> vocabulary scan -> posting lists
-    // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
-    orr::KwView kw{nullptr, 0, nullptr, nullptr};
-    bool kw_overflow_possible = false;
-    uint32_t kw_max_hits = 0;
-    if (n_terms_total > 0) {
-        std::vector<std::string_view> dterms;
-        std::unordered_map<std::string_view, uint32_t> dmap;
-        std::vector<uint32_t> qmeta((size_t)n_terms_total + (size_t)B + 1);   // [term -> distinct idx][query offsets]
-        for (uint32_t t = 0; t < n_terms_total; ++t) {
-            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
-            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
-            std::string_view sv(reinterpret_cast<const char *>(a.terms_utf8) + o, e - o);
-            auto it = dmap.find(sv);
-            if (it == dmap.end()) {
-                it = dmap.emplace(sv, (uint32_t)dterms.size()).first;
-                dterms.push_back(sv);
-            }
-            qmeta[t] = it->second;
-        }
-        for (int32_t b = 0; b <= B; ++b) qmeta[n_terms_total + b] = qoff[b] - t_begin;
-        const uint32_t TT = (uint32_t)dterms.size();
-        size_t pool_bytes = 0;
-        for (auto &d : dterms) pool_bytes += d.size();
-        // one pinned block, one upload: [ScanTerm x TT][qmeta][iota 0..64][term bytes]
-        const size_t off_terms = 0;
-        const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
-        const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
-        const size_t off_match = off_iota + sizeof(uint32_t) * 65;
-        const size_t off_pool = off_match + sizeof(orr::MatchTerm) * TT;
-        const size_t meta_bytes = off_pool + pool_bytes + 16;
-        ORR_TRY(idx->pin_meta.reserve(meta_bytes));
-        ORR_TRY(idx->ws_meta.reserve(meta_bytes));
-        uint8_t *hm = idx->pin_meta.as<uint8_t>();
-        orr::ScanTerm *st = reinterpret_cast<orr::ScanTerm *>(hm + off_terms);
-        uint32_t cursor = 0;
-        for (uint32_t t = 0; t < TT; ++t) {
-            st[t].off = cursor;
-            st[t].len = (uint32_t)dterms[t].size();
-            uint32_t pre = 0, msk = 0;
-            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
-                pre |= (uint32_t)(uint8_t)dterms[t][k] << (8 * k);
-                msk |= 0xFFu << (8 * k);
-            }
-            st[t].prefix = pre;
-            st[t].mask = msk;
-            orr::MatchTerm &mt = reinterpret_cast<orr::MatchTerm *>(hm + off_match)[t];
-            memset(&mt, 0, sizeof(mt));
-            mt.len = st[t].len;
-            for (uint32_t k = 0; k < 16 && k < st[t].len; ++k) {
-                mt.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
-                mt.m[k >> 2] |= 0xFFu << (8 * (k & 3));
-            }
-            memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
-            cursor += st[t].len;
-        }
-        memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
-        uint32_t *iota = reinterpret_cast<uint32_t *>(hm + off_iota);
-        for (uint32_t i = 0; i < 65; ++i) iota[i] = i;
-
-        const int64_t V = idx->n_tokens;
-        const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
-        const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
-        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, 16u << 20);
-        ORR_TRY(ensure_vlong(idx));
-        const int64_t VL = idx->n_vlong;
-        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
-        ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
-        ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
-        ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
-        hipStream_t k = idx->stream_kw;
-        uint8_t *dm = idx->ws_meta.as<uint8_t>();
-        HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
-        HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, sizeof(uint32_t) * (size_t)TT * (size_t)words, k));
-        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
-        if (V > 0) {
-            const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
-            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
-                Timed t(idx, "vocab_match", 0.0, k);
-                HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
-                                                      reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
-                                                      idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
-            }
-            if (VL > 0) {   // longer tokens: every distinct term is its own 1-term "query" of the wave-per-token scan
-                {
-                    Timed t(idx, "vocab_scan", 0.0, k);
-                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(), VL,
-                                                   dm + off_pool, d_terms, (int32_t)TT, reinterpret_cast<const uint32_t *>(dm + off_iota),
-                                                   idx->ws_vmatch.as<uint16_t>(), k));
-                }
-                {
-                    Timed t(idx, "vocab_hits", 0.0, k);
-                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VL, (int32_t)TT, idx->vlong_id.as<uint32_t>(), idx->d_post_off,
-                                                   idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
-                }
-            }
-            {
-                Timed t(idx, "expand_hits", 0.0, k);
-                HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
-                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k));
-            }
-        }
-        HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
-        kw.bitmaps = idx->ws_bitmaps.as<uint32_t>();
-        kw.words_per_term = words;
-        kw.q_term_idx = reinterpret_cast<const uint32_t *>(dm + off_qmeta);
-        kw.q_term_off = kw.q_term_idx + n_terms_total;
-        kw_overflow_possible = want_hits > (uint64_t)max_hits;
-        kw_max_hits = max_hits;
-    }
-
-    g_ht.mark(1);
     // ---- per-query constants (exact normA needs the vectors on the host)
     const bool batched_score = (B >= 4 || ts_stream) && kprime <= orr::kSelWidth;     // per-row pieces once per batch
     if (q_download_pending) HIP_TRY(hipEventSynchronize(idx->ev_q));
