@@ -182,6 +182,8 @@ struct orr_index {
     DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero, ws_norm_a;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
+    size_t bitmaps_clean = 0;          // leading bytes of ws_bitmaps known to be zero (cleared again behind every search)
+    const void *bitmaps_clean_of = nullptr;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm;
     hipEvent_t ev_q = nullptr;
 
@@ -1382,6 +1384,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     // needs the bitmaps, so this chain is the critical path of a batch): distinct terms -> vocabulary scan -> posting lists
     // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
     orr::KwView kw{nullptr, 0, nullptr, nullptr};
+    size_t bm_bytes = 0, bm_clean_before = 0;
     bool kw_overflow_possible = false;
     uint32_t kw_max_hits = 0;
     if (n_terms_total > 0) {
@@ -1455,12 +1458,21 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const int64_t VL = idx->n_vlong;
         ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
         ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
+        // The term bitmaps must start out zero.  Every search clears what it used again when it is done (on this side
+        // stream, behind its last kernel, while the host finishes the batch), so the next one only clears what lies
+        // beyond: the memset (270 MB at 1024 queries x 1M rows) leaves the critical path of the keyword chain.
+        bm_bytes = sizeof(uint32_t) * (size_t)TT * (size_t)words;
+        size_t bm_clean = idx->bitmaps_clean_of == idx->ws_bitmaps.p ? idx->bitmaps_clean : 0;
+        idx->bitmaps_clean = 0;                        // until this search has cleaned up after itself
+        idx->bitmaps_clean_of = idx->ws_bitmaps.p;
+        bm_clean_before = bm_clean;
         ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
         ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
         hipStream_t k = idx->stream_kw;
         uint8_t *dm = idx->ws_meta.as<uint8_t>();
         HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
-        HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, sizeof(uint32_t) * (size_t)TT * (size_t)words, k));
+        if (bm_clean < bm_bytes)
+            HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(idx->ws_bitmaps.p) + bm_clean, 0, bm_bytes - bm_clean, k));
         HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
         if (V > 0) {
             const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
@@ -1908,6 +1920,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     }
     g_ht.mark(3);
     HIP_TRY(hipStreamSynchronize(s));
+    if (bm_bytes) {            // every kernel that read the bitmaps is done: clear them for the next search
+        HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, bm_bytes, idx->stream_kw));
+        idx->bitmaps_clean = std::max(bm_bytes, bm_clean_before);
+    }
     if (dev_norms) memcpy(idx->h_norm_a.data(), idx->pin_norm.p, sizeof(double) * (size_t)B);
     g_ht.mark(4);
     collect_events(idx);
