@@ -292,8 +292,14 @@ def main():
                 # and is bound by streaming the shadow once (N*D bytes of int8 rows, 2*N*D of bf16 ones)
                 bytes_per_launch = sc["algo_bytes"] / sc["launches"]
                 achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                traffic_live = None
+                if os.path.exists(pmc_path) and (rows, dim) == (1_000_000, 3072) and world * B_local <= 32 and gname == "screen_i8_fused":
+                    with open(pmc_path) as f:     # measured with --batch 32 (one live query tile), committed with the profiles
+                        traffic_live = json.load(f)["kernels"].get("orr::screen_bf16_kernel<true, 0, true, 1> (bench.py --batch 32)", {}) \
+                            .get("hbm_bytes_per_launch_corrected")
                 roofline = {"bound": "hbm", "kernel": gname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_live,
+                            "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic_live else None,
                             "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
             else:
                 flops = 2.0 * (world * B_local) * rows * dim
