@@ -22,10 +22,25 @@ TERM_SLOT = 256        # bytes reserved per query for its packed terms
 
 def _slots_from_packed(pool: np.ndarray, toff: np.ndarray, qoff: np.ndarray) -> np.ndarray:
     """ABI term arrays -> one TERM_SLOT-byte slot per query: [n][len_0 .. len_{n-1}][bytes...], zero padded.
-    Vectorised: a batch of 1024 queries costs a fraction of a millisecond."""
+    Vectorised: a batch of 1024 queries costs a fraction of a millisecond; a handful of queries (the
+    one-query-per-rank step of the bench) is quicker in plain Python than through a dozen numpy calls."""
     B = int(qoff.shape[0]) - 1
     slots = np.zeros((B, TERM_SLOT), dtype=np.uint8)
     if B == 0:
+        return slots
+    if B <= 4:
+        to, qo = toff.tolist(), qoff.tolist()
+        raw = pool.tobytes()
+        for b in range(B):
+            t0, t1 = qo[b], qo[b + 1]
+            lens = [to[t + 1] - to[t] for t in range(t0, t1)]
+            if t1 - t0 > 255 or (lens and max(lens) > 255):
+                raise ValueError("term longer than 255 bytes" if lens and max(lens) > 255 else
+                                 "query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
+            body = bytes([t1 - t0]) + bytes(lens) + raw[to[t0]:to[t1]]
+            if len(body) > TERM_SLOT:
+                raise ValueError("query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
+            slots[b, :len(body)] = np.frombuffer(body, dtype=np.uint8)
         return slots
     toff = toff.astype(np.int64)
     qoff = qoff.astype(np.int64)
@@ -48,6 +63,20 @@ def _slots_from_packed(pool: np.ndarray, toff: np.ndarray, qoff: np.ndarray) -> 
 def _packed_from_slots(slots: np.ndarray) -> PackedTerms:
     """The inverse, for all gathered queries at once."""
     B = int(slots.shape[0])
+    if B <= 16:                                             # a few queries: plain Python beats the masked gathers below
+        pool, toff, qoff = bytearray(), [0], [0]
+        for row in slots:
+            raw = row.tobytes()
+            n = raw[0]
+            at = 1 + n
+            for ln in raw[1:1 + n]:
+                pool += raw[at:at + ln]
+                at += ln
+                toff.append(len(pool))
+            qoff.append(len(toff) - 1)
+        pool.append(0)
+        return PackedTerms((np.frombuffer(bytes(pool), dtype=np.uint8), np.asarray(toff, dtype=np.uint32),
+                            np.asarray(qoff, dtype=np.uint32)))
     n = slots[:, 0].astype(np.int64)
     col = np.arange(TERM_SLOT, dtype=np.int64)[None, :]
     len_mask = (col >= 1) & (col < 1 + n[:, None])

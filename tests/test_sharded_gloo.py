@@ -79,7 +79,16 @@ def test_term_slots_round_trip_for_a_whole_batch():
     assert all(np.array_equal(a, b) for a, b in zip(packed, back.arrays))
     assert [back[b] for b in range(len(batch))] == batch and list(back) == batch
     assert all(np.array_equal(a, b) for a, b in zip(P.pack_terms(back), packed))      # PackedTerms passes through
-    with pytest.raises(ValueError):
-        sh._slots_from_packed(*P.pack_terms([[b"y" * 256]]))
-    with pytest.raises(ValueError):
-        sh._slots_from_packed(*P.pack_terms([[b"y" * 200, b"z" * 100]]))
+    # a few queries take plain-Python paths, more the vectorised ones: every size round-trips to the same arrays
+    rng = np.random.default_rng(3)
+    for size in (1, 2, 4, 5, 16, 17, 40):
+        many = [[bytes(rng.integers(97, 123, int(rng.integers(1, 12))).astype(np.uint8)) for _ in range(int(rng.integers(0, 6)))]
+                for _ in range(size)]
+        pk = P.pack_terms(many)
+        sl = sh._slots_from_packed(*pk)
+        bk = sh._packed_from_slots(sl)
+        assert list(bk) == many and all(np.array_equal(a, b) for a, b in zip(pk, bk.arrays)), size
+        assert np.array_equal(sl, np.stack([sh._slots_from_packed(*P.pack_terms([q]))[0] for q in many])), size
+    for bad in ([[b"y" * 256]], [[b"y" * 200, b"z" * 100]], [[b"a"], [b"y" * 256], [], [], []], [[b"q"] * 256]):
+        with pytest.raises(ValueError):
+            sh._slots_from_packed(*P.pack_terms(bad))
