@@ -30,8 +30,10 @@ struct EpiParked { float a; uint32_t idx; };
 template <int NI, int NJ, bool RESCORED>
 __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int qbase, int64_t colbase, int32_t B,
                                                int64_t n_rows, const FusedEpilogue &epi, int lane, EpiParked *queue,
-                                               int queue_stride)
+                                               int queue_stride, uint32_t idx_salt = 0)
 {
+    // idx_salt: zero, but opaque to the compiler when the caller runs this inside a loop over output tiles -- it
+    // keeps the 128 constant tags of the parked entries from being hoisted out of that loop into registers.
     const int fr = lane & 31, fh = lane >> 5;
     float rb[NJ], rr[NJ], ea[NJ], eb[NJ];
     int64_t cols[NJ];
@@ -79,7 +81,7 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
                 if (!drop) {
                     if (parked < kEpiQueue) {
                         EpiParked pk;
-                        pk.a = a; pk.idx = (uint32_t)((i * 16 + e) * NJ + j);
+                        pk.a = a; pk.idx = (uint32_t)((i * 16 + e) * NJ + j) + idx_salt;
                         queue[parked * queue_stride] = pk;
                     } else if (RESCORED) {
                         const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
@@ -98,7 +100,8 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
     }
     if (parked > kEpiQueue) parked = kEpiQueue;
     for (int s = 0; s < parked; ++s) {
-        const EpiParked pk = queue[s * queue_stride];
+        EpiParked pk = queue[s * queue_stride];
+        pk.idx -= idx_salt;
         const int j = (int)(pk.idx % NJ), ie = (int)(pk.idx / NJ), e = ie & 15, i = ie >> 4;
         const int qi = qbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         const int64_t col = colbase + j * 32 + fr;

@@ -80,30 +80,55 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     constexpr int LI = LIVE >= 4 ? 4 : LIVE;                               // query tiles a multiplying wave owns
     const bool active = LIVE == 8 || wr == 0;
     constexpr int kPiecesActive = LIVE == 8 ? 4 : 3, kPiecesIdle = LIVE <= 2 ? 2 : 3;
+    // PERSISTENT: a workgroup walks the output tiles id = blockIdx.x, + gridDim.x, ... (the launcher starts one per
+    // CU).  The ring of K-tiles runs on across output tiles: while the last K-tiles of one are multiplied, the
+    // requests that used to be spare copies fetch the first K-tiles of the next, which then arrive during the
+    // epilogue (whose parking queue lives in the one stage that is free at that point).
     // ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
-    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-    const int mt = slot_id % n_mtiles, nt = (slot_id / n_mtiles) * 8 + xcd;
-    if (nt >= n_ntiles) return;
+    const int total_ids = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    auto valid_from = [&](int id) {                                         // first id >= the given one (in this workgroup's walk) with a row tile
+        while (id < total_ids && ((id >> 3) / n_mtiles) * 8 + (id & 7) >= n_ntiles) id += gridDim.x;
+        return id;
+    };
+    const int T = I8 ? D / 64 : D / kScBK;
+    const bool stream_rows = n_mtiles == 1 && (flags & 1);
+    // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
+    const int fr = lane & 31, fh = lane >> 5;
+    // ONE per-lane value addresses every fragment (read_frag): row = tile row + (lane & 31), 16-byte slot = chunk ^ ((row >> 2) & 3)
+    // with chunk = 2 ks + (lane >> 5); ks = 1 flips bit 5 of the address, the B fragments lie a wave-uniform distance behind
+    const int b_delta = kScImage + (wc * 64 - wr * 128) * 64;
+    const uint32_t lane_off = (uint32_t)(wave * 1024 + lane * 16);
+    int ring0 = 0;                                                          // stage of this output tile's K-tile 0
+    bool first = true;
+    for (int id = valid_from(blockIdx.x); id < total_ids;) {
+    const int next_id = valid_from(id + gridDim.x);
+    const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
     const int64_t n0 = row_first + (int64_t)nt * kScBN;
     const int b0 = mt * kScBM;
 
     // tiled operands: K-tile t of this workgroup's query tile / row tile is 16 KiB at base + t * 16 KiB;
     // piece g of a tile (g < 2: A image, g >= 2: B image) is the KiB (g & 1) * 8 + wave of it
-    const int T = I8 ? D / 64 : D / kScBK;
-    const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * T) * kScImage + wave * 1024 + lane * 16;
-    const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * T) * kScImage + wave * 1024 + lane * 16;
-    const bool stream_rows = n_mtiles == 1 && (flags & 1);
+    // (uniform bases: they live in scalar registers; one per-lane offset serves all of them)
+    const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * T) * kScImage;
+    const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * T) * kScImage;
+    // K-tiles T, T+1, ...: the first ones of the next output tile, or (last output tile) spare copies of this one's last
+    const bool has_next = next_id < total_ids;
+    const int nmt = has_next ? (next_id >> 3) % n_mtiles : mt, nnt = has_next ? ((next_id >> 3) / n_mtiles) * 8 + (next_id & 7) : nt;
+    const unsigned char *a_nxt = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)nmt * T) * kScImage;
+    const unsigned char *b_nxt = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nnt) * T) * kScImage;
     auto issue_piece = [&](int t, int g) {
-        const int tc = t < T ? t : T - 1;                                   // past the end: a spare copy of the last tile
-        unsigned char *base = lds + (t % kScNS) * kScStage + wave * 1024 + (g & 1) * 8192 + (g >> 1) * kScImage;
+        const bool over = t >= T;
+        const int tc = !over ? t : has_next ? t - T : T - 1;
+        const unsigned char *a_from = (over && has_next ? a_nxt : a_src) + lane_off, *b_from = (over && has_next ? b_nxt : b_src) + lane_off;
+        unsigned char *base = lds + ((ring0 + t) % kScNS) * kScStage + wave * 1024 + (g & 1) * 8192 + (g >> 1) * kScImage;
         if (MODE == 2 || (MODE == 4 && g < 2) || (MODE == 5 && g >= 2)) return;
         if (LIVE < 8 && g == 1) return;                                     // query rows 128..255: padding nobody reads
         if (LIVE <= 2 && g == 0 && wr != 0) return;                         // query rows 64..127 likewise (KiB 4..7 of the piece)
         // rows are streamed once when the whole batch fits one query tile: non-temporal, so they do not push
         // the query images (re-read by every workgroup) out of L2
-        if (g < 2) glds16<0>(a_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
-        else if (stream_rows) glds16<2>(b_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
-        else glds16<0>(b_src + (int64_t)tc * kScImage + (g & 1) * 8192, base);
+        if (g < 2) glds16<0>(a_from + (int64_t)tc * kScImage + (g & 1) * 8192, base);
+        else if (stream_rows) glds16<2>(b_from + (int64_t)tc * kScImage + (g & 1) * 8192, base);
+        else glds16<0>(b_from + (int64_t)tc * kScImage + (g & 1) * 8192, base);
     };
 
     typename std::conditional<I8, i32x16v, f32x16>::type acc[LI][2];
@@ -114,19 +139,18 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
-    // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
-    const int fr = lane & 31, fh = lane >> 5;
-    const int s0 = fh ^ ((fr >> 2) & 3);                                    // slot of ks = 0; ks = 1 flips bit 1
-    const int a_row = (wr * 128 + fr) * 64, b_row = kScImage + (wc * 64 + fr) * 64;
-
     struct Frag { bf16x8 a[LI], b[2]; };
     auto read_frag = [&](Frag &f, int t, int ks) {
-        const unsigned char *st = lds + (t % kScNS) * kScStage;
-        const int so = ((2 * ks) ^ s0) * 16;
+        // (recomputed from the lane id every time, behind an opaque copy: kept in a register across the K loop it is
+        // the value the compiler spills, and the reload comes with an s_waitcnt vmcnt(0) that drains the ring)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int frag = (wr * 128 + (ln & 31)) * 64 + (((ln >> 5) ^ ((ln >> 2) & 3)) << 4);
+        const unsigned char *st = lds + ((ring0 + t) % kScNS) * kScStage + (frag ^ (ks * 32));
 #pragma unroll
-        for (int i = 0; i < LI; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + a_row + i * 2048 + so);
+        for (int i = 0; i < LI; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_row + j * 2048 + so);
+        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_delta + j * 2048);
     };
 
 #define ORR_SB __builtin_amdgcn_sched_barrier(0)
@@ -166,7 +190,8 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #pragma unroll
     for (int t = 0; t < kScNS - 1; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) issue_piece(t, g);
+        for (int g = 0; g < 4; ++g) if (first) issue_piece(t, g);
+    first = false;
     if (active) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesActive * (kScNS - 2)) : "memory");
         Frag fa0, fa1, fb0, fb1;
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #undef ORR_TILE
 #undef ORR_MM
 #undef ORR_SB
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the spare pieces of the last tiles
+    if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces of the last tiles
 
     if (!FUSED) {
         if (active)
@@ -205,20 +230,38 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
                 }
             }
     } else {
-        __syncthreads();                                                    // every wave is done with the operand images
-        if (!active) return;
-        if constexpr (I8) {
-            f32x16 accf[LI][2];                                             // |I| <= 3072 * 127^2: the conversion costs at most 2^-24
+        // every wave is done with the stage the queue takes over (its fragment reads were consumed by its MFMAs); a bare
+        // barrier: __syncthreads() would also wait for the next output tile's first K-tiles, which are meant to arrive
+        // during the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the parking queue of the epilogue: the stage of this tile's last K-tile, the only one no request is bound for
+        EpiParked *queue = reinterpret_cast<EpiParked *>(lds + ((ring0 + T - 1) % kScNS) * kScStage) + tid;
+        // The epilogue's inputs are laundered once per output tile: otherwise everything it derives from them is
+        // hoisted out of the persistent loop and stays live across the K loop, whose registers are all spoken for
+        // (the compiler then spilt two values INSIDE it, with an s_waitcnt vmcnt(0) per K-tile to get them back).
+        FusedEpilogue ep = epi;
+        asm volatile("" : "+s"(ep.rowc), "+s"(ep.qc), "+s"(ep.tau), "+s"(ep.qf), "+s"(ep.count_planes), "+s"(ep.plane_stride),
+                          "+s"(ep.i8_rowf), "+s"(ep.i8_qs1), "+s"(ep.cnt), "+s"(ep.buf));
+        asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
+        uint32_t salt = 0;
+        asm volatile("" : "+s"(salt));
+        if (active) {
+            if constexpr (I8) {
+                f32x16 accf[LI][2];                                         // |I| <= 3072 * 127^2: the conversion costs at most 2^-24
 #pragma unroll
-            for (int i = 0; i < LI; ++i)
+                for (int i = 0; i < LI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) accf[i][j][e] = (float)acc[i][j][e];
-            fused_epilogue<LI, 2, true>(accf, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
-        } else {
-            fused_epilogue<LI, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, epi, lane, reinterpret_cast<EpiParked *>(lds) + tid, 512);
+                        for (int e = 0; e < 16; ++e) accf[i][j][e] = (float)acc[i][j][e];
+                fused_epilogue<LI, 2, true>(accf, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane, queue, 512, salt);
+            } else {
+                fused_epilogue<LI, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane, queue, 512, salt);
+            }
         }
+    }
+    ring0 = (ring0 + T) % kScNS;
+    id = next_id;
     }
 }
 
@@ -620,6 +663,22 @@ __global__ __launch_bounds__(256) void i8_tile_queries_kernel(const int8_t *__re
     }
 }
 
+// Workgroups to start for the screening GEMM: one per CU (it holds all of a CU's LDS), each walking its share of
+// the output tiles; a multiple of 8 keeps an id's XCD fixed along the walk.  ORR_SCREEN_PERSIST=0: one per tile.
+// k_tiles = K-tiles per output tile (D / 64 for int8, D / 32 for bf16).
+static int64_t screen_grid(int64_t tiles, int32_t k_tiles)
+{
+    if (k_tiles < kScNS - 1) return tiles;    // the requests of a tile reach kScNS - 1 K-tiles ahead: never past the next output tile
+    static const int64_t per_launch = [] {
+        const char *e = getenv("ORR_SCREEN_PERSIST");
+        if (e && atoi(e) == 0) return (int64_t)0;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return (int64_t)0;
+        return (int64_t)(cus / 8 * 8);
+    }();
+    return per_launch > 0 && tiles > per_launch ? per_launch : tiles;
+}
+
 hipError_t launch_i8_tile_queries(const void *q1_linear, int32_t B, int32_t D, void *tiled, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
@@ -646,7 +705,7 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, true, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true, L>), dim3((unsigned)blocks), dim3(512), kScLds, s, \
+        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi); } while (0)
     if (live_max == 8 || B > 128) ORR_LAUNCH_I8(8);
@@ -671,7 +730,7 @@ hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_t
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<false, 0, true, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<false, 0, true, L>), dim3((unsigned)blocks), dim3(512), kScLds, s, \
+        hipLaunchKernelGGL((screen_bf16_kernel<false, 0, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, 0, none); } while (0)
     if (B > 128) ORR_LAUNCH_I8D(8);
@@ -793,14 +852,14 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M, false>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<F, M, false>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
+        hipLaunchKernelGGL((screen_bf16_kernel<F, M, false>), dim3((unsigned)screen_grid(blocks, D / kScBK)), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, E); } while (0)
     static const int live_max = [] { const char *e = getenv("ORR_SCREEN_LIVE"); return e ? atoi(e) : 0; }();   // 8: always the full tile
 #define ORR_LAUNCH_LIVE(L) do { \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, false, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, false, L>), dim3((unsigned)blocks), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
+        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, false, L>), dim3((unsigned)screen_grid(blocks, D / kScBK)), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, *epi); } while (0)
     if (epi) {
         if (live_max == 8 || B > 128) ORR_LAUNCH_LIVE(8);
