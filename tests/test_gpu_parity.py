@@ -633,6 +633,27 @@ def test_two_stage_pass_at_a_dimension_that_is_a_multiple_of_256():
         for b in sorted({0, min(1, nb - 1), nb - 1}):
             orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (b0, nb, b)
+    # more than one 256-query tile: the persistent workgroups of the screening GEMM walk (query tile, row tile) pairs
+    B2 = 300
+    q2 = rng.standard_normal((B2, dim)).astype(np.float32)
+    q2[255] = emb[77_777]
+    q2[256] = emb[n - 1]
+    q2[299] = emb[123_456] * np.float32(2.0)
+    t2 = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B2)]
+    terms2 = [P.text.query_terms(t) for t in t2]
+    idx.set_option("two_stage", 0)
+    plain = idx.search(q2, terms2, NOW, 10, candidate_limit=n)
+    idx.set_option("two_stage", 1)
+    idx.set_profiling(True)
+    got = idx.search(q2, terms2, NOW, 10, candidate_limit=n)
+    st = idx.kernel_stats()
+    idx.set_profiling(False)
+    assert st["screen_i8_fused"]["launches"] == 1 and "gemm_dot_bf16x3" not in st, sorted(st)
+    assert all(np.array_equal(x, y) for x, y in zip(plain, got))
+    assert got[0][255, 0] == 77_777 and got[0][256, 0] == n - 1 and got[0][299, 0] == 123_456
+    for b in (0, 255, 256, 299):
+        orow, osc, _ = corpus.search(q2[b], t2[b], NOW, 10, candidate_limit=n, threads=8)
+        assert list(got[0][b, :got[2][b]]) == list(orow) and np.array_equal(got[1][b, :got[2][b]], osc), b
     import torch
     qd = torch.from_numpy(qs).to("cuda:0")                                 # device-resident batch: norms computed on the device
     for nb in (70, 20, 3):
