@@ -225,9 +225,9 @@ int64_t orr_index_live_rows(const orr_index *idx);
  *                    best score, and re-score those in the reference arithmetic on the device.
  *                    1: the product reads a shadow copy of the embeddings, built at the first such search (or
  *                    now if the index is sealed and the option is set explicitly): int8 with one scale per row
- *                    and a per-pair error bound when dim % 128 == 0 (+25 % HBM; a stream for 1..8 queries, an
+ *                    and a per-pair error bound when dim % 128 == 0 (+25 % HBM; a stream for 1..4 queries, an
  *                    int8 MFMA GEMM for more), bf16 otherwise (+50 % HBM, bound 2^-7 |q||e|); silently falls
- *                    back to 2 when the shadow does not fit.  2: no shadow: 9+ queries convert the fp32 rows to
+ *                    back to 2 when the shadow does not fit.  2: no shadow: 5+ queries convert the fp32 rows to
  *                    bf16 inside the kernel, fewer run the exact kernel.  0: exact kernel (1..4 queries) /
  *                    streaming or split-bf16 MFMA pass over all rows. */
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
