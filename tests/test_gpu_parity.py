@@ -698,6 +698,45 @@ def test_device_resident_query_batches_get_the_same_norms_as_host_ones(n, dim):
     idx.close()
 
 
+def test_two_stage_pass_on_the_bf16_shadow_at_dim_192():
+    """dim % 128 != 0: no int8 shadow, the two-stage pass runs on the bf16 one -- streaming screen for 1..8 queries,
+    the bf16 screening GEMM (persistent workgroups: 782 row tiles, 6 K-tiles each) beyond, split-bf16 prefix."""
+    P = pkg()
+    rng = np.random.default_rng(83)
+    n, dim = 200_000, 192
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm"])
+    contents = [" ".join(w) for w in words[rng.integers(0, len(words), (n, 4))]]
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], [c.encode() for c in contents[r0:r0 + 50_000]])
+    idx.seal()
+    B = 300
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[0] = emb[n - 5]
+    qs[256] = emb[31_337]
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    corpus = orc.OracleCorpus(emb, created, contents)
+    idx.set_option("two_stage", 0)
+    plain = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    idx.set_option("two_stage", 1)
+    for b0, nb, kernel in ((0, 1, "screen_gemv_bf16"), (3, 8, "screen_gemv_bf16"), (0, 20, "screen_bf16_fused"),
+                           (0, 100, "screen_bf16_fused"), (0, 300, "screen_bf16_fused")):
+        idx.set_profiling(True)
+        got = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
+        st = idx.kernel_stats()
+        idx.set_profiling(False)
+        assert kernel in st and "screen_i8_fused" not in st and "screen_gemv_i8" not in st, sorted(st)
+        assert all(np.array_equal(x[b0:b0 + nb], y) for x, y in zip(plain, got)), (b0, nb)
+    assert plain[0][0, 0] == n - 5 and plain[0][256, 0] == 31_337
+    for b in (0, 1, 256, 299):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+        assert list(plain[0][b, :plain[2][b]]) == list(orow) and np.array_equal(plain[1][b, :plain[2][b]], osc), b
+    idx.close()
+
+
 def test_empty_and_degenerate_inputs():
     """Empty corpus, rows with empty content, queries without terms or vectors, API misuse."""
     P = pkg()
