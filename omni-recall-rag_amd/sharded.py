@@ -114,6 +114,21 @@ class ShardedRecallSearch:
         # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit) -> records [B,kprime+1]
         self._shard_search = shard_search or (lambda q, t, now, kp, lim, out=None:
                                               self.index.search_shard(q, t, now, kp, lim, out=out))
+        self._pinned = {}                      # name -> pinned host staging tensor (device runs only)
+
+    def _to_host(self, name: str, t: torch.Tensor) -> np.ndarray:
+        """Device tensor -> numpy through a reused pinned buffer (one asynchronous copy + one stream sync instead of
+        a pageable synchronous copy); plain .numpy() on CPU rehearsals."""
+        if t.device.type != "cuda":
+            return t.numpy()
+        buf = self._pinned.get(name)
+        if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
+            buf = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
+            self._pinned[name] = buf
+        view = buf[:t.numel()].view(t.shape)
+        view.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return view.numpy()
 
     def search(self, q_local: torch.Tensor, terms_local: Sequence[Sequence[bytes]], now_ticks: int, topk: int,
                candidate_limit: int, kprime: int = 32):
@@ -138,7 +153,7 @@ class ShardedRecallSearch:
             allq = send
         B = W * B_local
         q_all = allq[:, :vec_bytes].contiguous().view(torch.float32).reshape(B, dim) if dim else None
-        allq_host = allq.cpu().numpy()              # ONE download: vectors (for the exact normA) + terms
+        allq_host = self._to_host("queries", allq)   # ONE download: vectors (for the exact normA) + terms
         q_host = np.ascontiguousarray(allq_host[:, :vec_bytes]).view(np.float32).reshape(B, dim) if dim else None
         terms_all = _packed_from_slots(allq_host[:, vec_bytes:])   # ABI form, packed once for both calls below
 
@@ -153,7 +168,7 @@ class ShardedRecallSearch:
                 dist.all_gather_into_tensor(allrec, mine, group=self.group)
             else:
                 allrec = mine
-            recs = allrec.cpu().numpy().view(CAND_DTYPE).reshape(W, B, kprime + 1)
+            recs = self._to_host("records", allrec).view(CAND_DTYPE).reshape(W, B, kprime + 1)
             # Every rank finishes EVERY query from the same gathered bytes, so all ranks reach the
             # same "escalate or not" decision without another collective.
             rows, scores, counts, unc = merge_candidates(recs, self.index_dim, q_host, terms_all, now_ticks, topk)
