@@ -1185,6 +1185,7 @@ struct BatchArgs {
     bool force_exact = false;      // skip the MFMA candidate pass (escalation after a failed certificate)
     mutable bool used_mfma = false; // set by run_shard
     bool no_fuse = false;          // keep the batched pass unfused (retry after a candidate-buffer overflow)
+    orr_candidate *out_dev = nullptr;   // orr_search_shard with a device-resident `out`: the kernels write the records there
     mutable bool used_fused = false;
 };
 
@@ -1325,6 +1326,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (direct_host) {
         ORR_TRY(idx->pin_cand.reserve(rec_bytes));
         d_cand = idx->pin_cand.as<orr_candidate>();        // pinned host memory is device-writable
+    } else if (a.out_dev) {
+        d_cand = a.out_dev;
     } else {
         ORR_TRY(idx->ws_cand.reserve(rec_bytes));
         d_cand = idx->ws_cand.as<orr_candidate>();
@@ -2070,6 +2073,11 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
     std::lock_guard<std::mutex> lock(idx->mu);
+    if (is_device_pointer(out)) {               // records written where the caller wants them (the all-gather's send buffer)
+        a.out_dev = out;
+        ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
+        return ORR_OK;
+    }
     ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
     HIP_TRY(hipMemcpy(out, idx->ws_cand.p, sizeof(orr_candidate) * (size_t)B * ((size_t)kprime + 1), hipMemcpyDefault));
     return ORR_OK;
