@@ -114,3 +114,52 @@ def test_merge_candidates_is_host_only_and_exact():
     for b in range(B):
         orow, osc, _ = corpus.search(qs[b], texts[b], 639144000000000000, k, candidate_limit=n)
         assert list(rows[b]) == list(orow) and np.array_equal(scores[b], osc) and counts[b] == k
+
+
+def test_large_merges_through_the_host_thread_pool_equal_query_by_query_merges():
+    """A merge of many records is shared out over the library's persistent host threads (queries are independent),
+    the exact norms of host-resident queries likewise; a second caller arriving meanwhile runs its work itself.
+    Same records query by query (single-threaded path), in one call (pool), and from four threads at once."""
+    import threading
+    P = pkg()
+    rng = np.random.default_rng(10)
+    B, S, kp, d, k = 700, 3, 32, 384, 10                  # 700 x 384 floats: the norms go through the pool as well
+    now = 639144000000000000
+    qs = rng.standard_normal((B, d)).astype(np.float32)
+    qs[5] = 0.0
+    terms = [[b"alpha", b"beta"][: b % 3] for b in range(B)]
+    recs = np.zeros((S, B, kp + 1), dtype=P.CAND_DTYPE)
+    recs["dot"] = rng.standard_normal((S, B, kp + 1)) * 5
+    recs["norm_b"] = rng.uniform(0.5, 30.0, (S, B, kp + 1))
+    recs["created_ticks"] = now - rng.integers(0, 300 * 864000000000, (S, B, kp + 1))
+    pos = np.arange(S * (kp + 1)).reshape(S, 1, kp + 1) + np.zeros((1, B, 1), dtype=np.int64)
+    recs["row_id"] = pos * 7 + 1
+    recs["order_key"] = pos
+    recs["matches"] = rng.integers(0, 3, (S, B, kp + 1)) % (np.array([len(t) for t in terms])[None, :, None] + 1)
+    recs["flags"] = P.native.ORR_CAND_DOT_EXACT
+    for s_, i_ in ((0, 3), (1, 4)):                       # two records that would win query 7 ...
+        recs["dot"][s_, 7, i_] = 1e4
+        recs["norm_b"][s_, 7, i_] = 1.0
+    recs["flags"][0, 7, 3] |= P.native.ORR_CAND_DEAD      # ... one of them of a deleted row: dropped by the finish
+    for s in range(S):
+        for b in range(B):
+            recs[s, b, kp] = (-np.inf, 0, 0, 0, -1, kp, kp, P.native.ORR_CAND_TRAILER)
+    whole = P.merge_candidates(recs, d, qs, terms, now, k)
+    assert whole[3] == 0 and (whole[2] == k).all()
+    for b in list(range(0, B, 37)) + [5, 7, B - 1]:
+        one = P.merge_candidates(recs[:, b:b + 1], d, qs[b:b + 1], terms[b:b + 1], now, k)
+        assert np.array_equal(one[0][0], whole[0][b]) and np.array_equal(one[1][0], whole[1][b]), b
+    dead_id, twin_id = int(recs["row_id"][0, 7, 3]), int(recs["row_id"][1, 7, 4])
+    assert dead_id not in set(int(r) for r in whole[0][7]) and int(whole[0][7, 0]) == twin_id
+    results = [None] * 4
+
+    def work(i):
+        results[i] = P.merge_candidates(recs, d, qs, terms, now, k)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r in results:
+        assert all(np.array_equal(x, y) for x, y in zip(r[:3], whole[:3])) and r[3] == 0
