@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <chrono>
+#include <pthread.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -342,7 +343,7 @@ public:
     void run(int n_tasks, const std::function<void(int)> &fn)
     {
         std::unique_lock<std::mutex> region(region_mu_, std::try_to_lock);
-        if (!region.owns_lock() || workers_.empty() || n_tasks <= 1) {
+        if (!region.owns_lock() || workers_.empty() || n_tasks <= 1 || forked_.load(std::memory_order_relaxed)) {
             for (int i = 0; i < n_tasks; ++i) fn(i);
             return;
         }
@@ -361,6 +362,8 @@ private:
     {
         for (int i = 0; i < n_workers; ++i) workers_.emplace_back([this] { loop(); });
         for (auto &w : workers_) w.detach();
+        // a forked child inherits this object but none of its threads: there every region runs in the caller
+        pthread_atfork(nullptr, nullptr, [] { forked_.store(true); });
     }
     void loop()
     {
@@ -377,6 +380,7 @@ private:
             if (--active_ == 0) cv_done_.notify_one();
         }
     }
+    static inline std::atomic<bool> forked_{false};
     std::mutex region_mu_, mu_;
     std::condition_variable cv_work_, cv_done_;
     std::vector<std::thread> workers_;

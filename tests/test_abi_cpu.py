@@ -163,3 +163,37 @@ def test_large_merges_through_the_host_thread_pool_equal_query_by_query_merges()
         t.join()
     for r in results:
         assert all(np.array_equal(x, y) for x, y in zip(r[:3], whole[:3])) and r[3] == 0
+
+
+def test_host_thread_pool_survives_a_fork():
+    """A forked child inherits the pool object but none of its threads: large merges there run in the caller
+    instead of waiting for workers that do not exist."""
+    import os
+    import signal
+    P = pkg()
+    rng = np.random.default_rng(11)
+    B, kp, d, k = 400, 32, 8, 5
+    now = 639144000000000000
+    qs = rng.standard_normal((B, d)).astype(np.float32)
+    terms = [[] for _ in range(B)]
+    recs = np.zeros((1, B, kp + 1), dtype=P.CAND_DTYPE)
+    recs["dot"] = rng.standard_normal((1, B, kp + 1))
+    recs["norm_b"] = 2.0
+    recs["created_ticks"] = now
+    recs["row_id"] = np.arange(kp + 1)[None, None, :]
+    recs["order_key"] = np.arange(kp + 1)[None, None, :]
+    recs["flags"] = P.native.ORR_CAND_DOT_EXACT
+    for b in range(B):
+        recs[0, b, kp] = (-np.inf, 0, 0, 0, -1, kp, kp, P.native.ORR_CAND_TRAILER)
+    want = P.merge_candidates(recs, d, qs, terms, now, k)          # starts the pool in this process
+    pid = os.fork()
+    if pid == 0:                                                   # child: no pytest machinery from here on
+        try:
+            signal.alarm(20)                                       # a wait for missing workers would end here
+            got = P.merge_candidates(recs, d, qs, terms, now, k)
+            ok = all(np.array_equal(x, y) for x, y in zip(got[:3], want[:3]))
+            os._exit(0 if ok else 3)
+        except BaseException:
+            os._exit(4)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
