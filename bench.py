@@ -98,12 +98,24 @@ def cpu_baseline(P, syn, args, n_total, torch, dev):
     corpus.search(qs[0], texts[0], syn.NOW_TICKS, args.topk, candidate_limit=m, threads=1)
     dt1 = time.perf_counter() - t1
     rows_per_s = m * nq / dt
+    # an optimised CPU variant beside the reference-faithful one, labelled as such -- cosine part only,
+    # fp32 BLAS GEMM over the same sample with precomputed norms (NOT the reference arithmetic), top-k by partition
+    norms = np.concatenate([np.sqrt(np.square(emb[i:i + 8192], dtype=np.float64).sum(axis=1)) for i in range(0, m, 8192)]).astype(np.float32)
+    qn = np.sqrt(np.square(qs, dtype=np.float64).sum(axis=1)).astype(np.float32)
+    t2 = time.perf_counter()
+    cos = (emb @ qs.T) / (norms[:, None] * qn[None, :] + np.float32(1e-30))
+    top = np.argpartition(-cos, args.topk, axis=0)[: args.topk]
+    dt2 = time.perf_counter() - t2
+    del cos, top
     return {
         "value": rows_per_s / args.rows_per_gpu, "unit": "queries/s", "cores": cores, "kind": "port",
         "sample": f"{nq} queries x {m} of {args.rows_per_gpu} rows x {args.dim}-d scored by the C oracle "
                   f"(reference arithmetic, full hybrid) on {cores} threads in {dt:.2f}s; "
                   f"value = row-rate / rows per query (linear extrapolation)",
         "single_thread_value": (m / dt1) / args.rows_per_gpu,
+        "optimised_variant": {"value": (m * nq / dt2) / args.rows_per_gpu, "unit": "queries/s",
+                              "what": "cosine part only: fp32 BLAS GEMM with precomputed norms + argpartition (numpy), "
+                                      "not the reference arithmetic, no keyword or recency term"},
     }
 
 
