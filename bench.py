@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the hybrid recall-search hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): 1M chunks x 3072-d fp32 PER GPU, top-k=10,
-full hybrid score (cosine + keyword + recency fused 0.7/0.2/0.1), candidate_limit =
-whole corpus.  Results are exact (reference arithmetic); by default the library screens the
-corpus through its bf16 shadow and re-scores the survivors from the fp32 master,
-so the dominant kernel streams 2*N*D bytes; `--set-option two_stage=0` restores the exact kernel
-over all 4*N*D bytes.  A step is one pass of the hot path over one batch: every rank
-originates ONE query; with N ranks the corpus is N x 1M rows, row-sharded, and each
-query is scored against ALL shards (queries all-gathered, per-shard top-k' records
-all-gathered over RCCL, exact host finish).  Weak scaling: per-GPU rows are fixed,
-corpus and query count grow with N.  value = queries answered per second, whole job.
+One GPU (`python bench.py [--gpus 1]`), headline = BASELINE.json configs[2], "C3":
+10M chunks x 3072-d fp32 resident on one MI355X, 256 queries per step, top-k = 10, full hybrid
+score (cosine + keyword + recency fused 0.7/0.2/0.1), candidate_limit = whole corpus.  The same JSON
+line carries a second leg, configs[1] "C2" (1M chunks, one query per step), the parity block (HIP path
+against the oracle on a candidate_limit prefix of the headline corpus) and the CPU baseline.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+N > 1 GPUs (`--gpus N`; started plainly it spawns `python -m torch.distributed.run` as a CHILD before
+anything touches a GPU, started under torch.distributed.run it is one rank): 12.5M rows per GPU (the
+per-GPU shape of configs[3]/[4], 100M rows over 8 GPUs), row-sharded, one process per GPU.  Rank 0
+originates a batch of 1024 queries per step (C5, full hybrid), broadcasts it, every rank scores all of
+them against its shard, ONE all-gather of per-shard top-k' records over RCCL, host merge.  Legs: C4
+(cosine only) with 1 and 256 queries per step.  Weak scaling: rows per GPU and queries per step are
+fixed, the corpus grows with N; value = queries answered per second by the whole job.
 
-Inputs are resident in HBM before the timed region; results land in host memory
-inside it.  The oracle is used here ONLY for the `cpu_baseline` leg.
+A step is one pass of the hot path over one batch.  Inputs are resident in HBM before the timed
+region; results land in host memory inside it.  Results are exact (the reference's arithmetic): the
+library screens the corpus through an int8 shadow with a rigorous per-pair bound and re-scores the
+survivors from the fp32 master in f32 x f32 -> f64.  The oracle is used here ONLY for
+the `cpu_baseline` / `parity` leg, never inside a timed GPU region.
 """
 from __future__ import annotations
 
@@ -25,6 +27,8 @@ import argparse
 import importlib
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -32,43 +36,106 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (no sparsity)
-MFMA_I8_PEAK_TOPS = 5000.0       # dense int8 MFMA peak (no sparsity)
+# Peaks the roofline fractions are priced against (MI355X_MICROARCH.md, chip-level parameters; dense, no
+# sparsity).  host_probe() re-reads what the box reports (CUs, max clock) and records it beside them.
+HBM_PEAK_GBS = 8000.0            # HBM3E spec; 6.29 TB/s is the measured copy ceiling
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_I8_PEAK_TOPS = 5000.0
+I8_CROSSOVER_B = MFMA_I8_PEAK_TOPS * 1e12 / (HBM_PEAK_GBS * 1e9) / 2.0     # queries per int8 row byte: 312.5
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--rows-per-gpu", type=int, default=0, help="0 = 10,000,000 on one GPU (C3), 12,500,000 per GPU on several (C4/C5)")
     ap.add_argument("--dim", type=int, default=3072)
-    ap.add_argument("--batch", type=int, default=1, help="queries originated per rank per step")
+    ap.add_argument("--batch", type=int, default=0, help="queries per step of the whole job; 0 = 256 on one GPU (C3), 1024 on several (C5)")
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="single-GPU runs: steps are issued from this many threads, each on its own search lane "
-                         "(orr_index_view), so the host finish and the small kernels of one step overlap the "
-                         "dominant kernel of another")
-    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra two-steps-in-flight measurement")
-    ap.add_argument("--no-terms", action="store_true", help="diagnostic: queries without keyword terms")
+    ap.add_argument("--no-legs", action="store_true", help="headline only: skip the C2 leg (one GPU) / the C4 legs (several)")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-steps-in-flight measurement of the C2 leg")
+    ap.add_argument("--clustered-leg", action="store_true", help="add a leg on a clustered corpus (64 centroids + 0.1 noise)")
+    ap.add_argument("--no-terms", action="store_true", help="headline without keyword terms (cosine + recency only)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
-                    help="orr_index_set_option on the shard before the run (e.g. two_stage=1)")
-    return ap.parse_args()
+                    help="orr_index_set_option on every shard before the run (e.g. two_stage=0)")
+    return ap.parse_args(argv)
 
 
-def build_shard(P, syn, torch, rank, rows, dim, n_total, dev, options=()):
+# ------------------------------------------------------------------------------------------------
+# host probes: all of them child processes, all before this process touches the GPU
+# ------------------------------------------------------------------------------------------------
+def _run_quiet(cmd, timeout=30):
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        return p.returncode, p.stdout.decode(errors="replace")
+    except FileNotFoundError:
+        return None, ""
+    except Exception as exc:                       # timeouts, permissions
+        return -1, repr(exc)
+
+
+def host_probe():
+    """dotnet, core counts, and what rocminfo says about the GPU."""
+    out = {"os_cpu_count": os.cpu_count()}
+    try:
+        out["cpus_in_affinity_mask"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    rc, txt = _run_quiet(["dotnet", "--version"])
+    out["dotnet"] = txt.strip().splitlines()[0] if rc == 0 and txt.strip() else "unavailable"
+    rc, txt = _run_quiet(["/opt/rocm/bin/rocminfo"])
+    if rc == 0:
+        agents = txt.split("*******")
+        for a in agents:
+            if "gfx950" in a and "Compute Unit" in a:
+                m_cu = re.search(r"Compute Unit:\s+(\d+)", a)
+                m_clk = re.search(r"Max Clock Freq\. \(MHz\):\s+(\d+)", a)
+                m_name = re.search(r"Marketing Name:\s+(.+)", a)
+                out["gpu"] = {"name": m_name.group(1).strip() if m_name else None,
+                              "compute_units": int(m_cu.group(1)) if m_cu else None,
+                              "max_clock_mhz": int(m_clk.group(1)) if m_clk else None}
+                break
+    gpu = out.get("gpu") or {}
+    if gpu.get("compute_units") and gpu.get("max_clock_mhz"):
+        # dense int8 MFMA: 32x32x32 x 2 ops per 32 cycles per SIMD, 4 SIMDs per CU
+        gpu["mfma_i8_peak_tops_at_max_clock"] = gpu["compute_units"] * 4 * 2048 * gpu["max_clock_mhz"] * 1e6 / 1e12
+    return out
+
+
+def spawn_ranks(args, argv):
+    """`--gpus N` started without a launcher: run torch.distributed.run as a CHILD (this process has not touched
+    the GPU and never will) and relay its output."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env)
+    raise SystemExit(p.returncode)
+
+
+# ------------------------------------------------------------------------------------------------
+# corpus and legs
+# ------------------------------------------------------------------------------------------------
+def build_shard(P, gen, torch, rank, rows, dim, n_total, dev, options=()):
     idx = P.RecallIndex(dim=dim, device=dev.index or 0, capacity_rows=rows, row_base=rank * rows)
     step = 32768
     for r0 in range(0, rows, step):
         m = min(step, rows - r0)
         g0 = rank * rows + r0
-        pool, off = syn.contents(g0, m, dev)
-        idx.append(syn.embeddings(g0, m, dim, dev), syn.created_ticks(g0, m, n_total, dev), pool, off)
-    torch.cuda.synchronize()
+        pool, off = gen.contents(g0, m, dev)
+        emb = gen.embeddings(g0, m, dim, dev)
+        created = gen.created_ticks(g0, m, n_total, dev)
+        torch.cuda.current_stream().synchronize()         # the library reads the tensors on its own stream
+        idx.append(emb, created, pool, off)
     idx.seal()
     for opt in options:
         name, _, value = opt.partition("=")
@@ -76,137 +143,63 @@ def build_shard(P, syn, torch, rank, rows, dim, n_total, dev, options=()):
     return idx
 
 
-def cpu_baseline(P, syn, args, n_total, torch, dev):
-    """The reference-faithful oracle (kind "port") timed on the host cores over a bounded sample."""
-    import numpy as np
-    from oracle import oracle_py as orc
-    m = min(args.cpu_sample_rows, args.rows_per_gpu)
-    nq = args.cpu_sample_queries
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    # the sample is generated on the GPU (same deterministic generator) and copied to the host
-    emb = torch.cat([syn.embeddings(r0, min(32768, m - r0), args.dim, dev).cpu() for r0 in range(0, m, 32768)]).numpy()
-    created = syn.created_ticks(0, m, n_total, dev).cpu().numpy()
-    pool, off = syn.contents(0, m, dev)
-    corpus = orc.OracleCorpus(emb, created, (pool.cpu().numpy(), off.cpu().numpy()))
-    qs = syn.query_vectors(0, nq, args.dim, n_total, dev).cpu().numpy()
-    texts = syn.query_texts(0, nq, n_total)
-    t0 = time.perf_counter()
-    for b in range(nq):
-        corpus.search(qs[b], texts[b], syn.NOW_TICKS, args.topk, candidate_limit=m, threads=cores)
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    corpus.search(qs[0], texts[0], syn.NOW_TICKS, args.topk, candidate_limit=m, threads=1)
-    dt1 = time.perf_counter() - t1
-    rows_per_s = m * nq / dt
-    # SURVEY 8(d): an optimised CPU variant beside the reference-faithful one, labelled as such -- cosine part only,
-    # fp32 BLAS GEMM over the same sample with precomputed norms (NOT the reference arithmetic), top-k by partition
-    norms = np.concatenate([np.sqrt(np.square(emb[i:i + 8192], dtype=np.float64).sum(axis=1)) for i in range(0, m, 8192)]).astype(np.float32)
-    qn = np.sqrt(np.square(qs, dtype=np.float64).sum(axis=1)).astype(np.float32)
-    t2 = time.perf_counter()
-    cos = (emb @ qs.T) / (norms[:, None] * qn[None, :] + np.float32(1e-30))
-    top = np.argpartition(-cos, args.topk, axis=0)[: args.topk]
-    dt2 = time.perf_counter() - t2
-    del cos, top
-    return {
-        "value": rows_per_s / args.rows_per_gpu, "unit": "queries/s", "cores": cores, "kind": "port",
-        "sample": f"{nq} queries x {m} of {args.rows_per_gpu} rows x {args.dim}-d scored by the C oracle "
-                  f"(reference arithmetic, full hybrid) on {cores} threads in {dt:.2f}s; "
-                  f"value = row-rate / rows per query (linear extrapolation)",
-        "single_thread_value": (m / dt1) / args.rows_per_gpu,
-        "optimised_variant": {"value": (m * nq / dt2) / args.rows_per_gpu, "unit": "queries/s",
-                              "what": "cosine part only: fp32 BLAS GEMM with precomputed norms + argpartition (numpy), "
-                                      "not the reference arithmetic, no keyword or recency term"},
-    }
+class Leg:
+    """One timed workload: W warm-up steps, then exactly K steps between barrier + synchronize."""
+
+    def __init__(self, name, workload, rows_per_gpu, n_total, batch, terms=True):
+        self.name, self.workload = name, workload
+        self.rows_per_gpu, self.n_total, self.batch, self.terms = rows_per_gpu, n_total, batch, terms
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
-    import __graft_entry__ as graft
-    P = graft.load_package()
-    syn = importlib.import_module(graft.PKG_NAME + ".synthetic")
-    sharded = importlib.import_module(graft.PKG_NAME + ".sharded")
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
-    rows, dim, B_local, k = args.rows_per_gpu, args.dim, args.batch, args.topk
-    n_total = rows * world
-    idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
-    # ORR_BENCH_FORCE_SHARDED=1 drives the sharded front-end (device tensors in, records out, host
-    # merge) even on one GPU: a rehearsal of the N>1 code path without RCCL
-    use_front = world > 1 or os.environ.get("ORR_BENCH_FORCE_SHARDED") == "1"
-    front = sharded.ShardedRecallSearch(idx, dim, dev) if use_front else None
-
+def run_leg(leg, args, env, idx, front, gen, overlap=False):
+    """Returns the leg's result dict on every rank (timings are the max over ranks)."""
+    P, torch, dist, dev, world, rank = env["P"], env["torch"], env["dist"], env["dev"], env["world"], env["rank"]
+    k, dim, B = args.topk, args.dim, leg.batch
     n_steps_total = args.warmup + args.steps
-    # queries for every step, generated up front and resident in HBM (rank r originates queries
-    # r*B_local .. of each step's global batch)
+    origin = rank == 0
+    # queries for every step, generated up front and resident in HBM; the tokenisation of the query texts (the host
+    # half of KeywordScore, RecallSearchService.cs:95-108) is timed separately and reported, not inside the steps
     q_steps, term_steps = [], []
-    for s in range(n_steps_total):
-        b0 = (s * world + rank) * B_local
-        q_steps.append(syn.query_vectors(b0, B_local, dim, n_total, dev))
-        # tokenised and packed into the ABI's term arrays up front, like the query vectors (host-side input preparation)
-        term_steps.append(P.PackedTerms(P.pack_terms([[] if args.no_terms else P.text.query_terms(t) for t in syn.query_texts(b0, B_local, n_total)])))
+    tok_s = 0.0
+    if origin or front is None:
+        for s in range(n_steps_total):
+            b0 = s * B
+            q_steps.append(gen.query_vectors(b0, B, dim, leg.n_total, dev))
+            texts = gen.query_texts(b0, B, leg.n_total)
+            t0 = time.perf_counter()
+            terms = [[] if not leg.terms else P.text.query_terms(t) for t in texts]
+            packed = P.PackedTerms(P.pack_terms(terms))
+            tok_s += time.perf_counter() - t0
+            term_steps.append(packed)
     torch.cuda.synchronize()
 
-    n_lanes = max(1, args.inflight) if front is None else 1
-    lanes = [idx] + [idx.view() for _ in range(n_lanes - 1)]
-
-    def step(s, lane=0):
+    def step(s, lane=None):
         if front is not None:
-            return front.search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, n_total)
-        return lanes[lane].search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
+            return front.search_from(0, q_steps[s] if origin else None, term_steps[s] if origin else None,
+                                     gen.NOW_TICKS, k, leg.n_total)
+        return (lane or idx).search(q_steps[s], term_steps[s], gen.NOW_TICKS, k, candidate_limit=leg.n_total)
 
     for s in range(args.warmup):
-        step(s, s % n_lanes)
-    for ln in lanes:
-        ln.set_profiling(True)
+        step(s)
+    idx.set_profiling(True)
+    idx.reset_search_stats()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    results = {}
     t0 = time.perf_counter()
-    if n_lanes == 1:
-        for s in range(args.warmup, n_steps_total):
-            results[s] = step(s)
-    else:
-        import threading
-
-        def run_lane(lane):
-            for s in range(args.warmup + lane, n_steps_total, n_lanes):
-                results[s] = step(s, lane)
-
-        threads = [threading.Thread(target=run_lane, args=(ln,)) for ln in range(n_lanes)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+    last = None
+    for s in range(args.warmup, n_steps_total):
+        last = step(s)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    last = results[n_steps_total - 1]
+    stats = idx.kernel_stats()
+    sstats = idx.search_stats()
+    idx.set_profiling(False)
 
-    stats = {}
-    for ln in lanes:
-        for name, v in ln.kernel_stats().items():
-            acc = stats.setdefault(name, {"launches": 0, "total_ms": 0.0, "algo_bytes": 0.0})
-            for key in acc:
-                acc[key] += v[key]
-        ln.set_profiling(False)
-
-    # Reported beside the headline, not as it: the same steps again with two of them in flight (two threads,
-    # the second on a view of the shard), which is how concurrent requests reach the service.
-    overlap = None
-    if front is None and n_lanes == 1 and not args.no_overlap_leg:
+    two = None
+    if overlap and front is None:
         import threading
         lane2 = None
         try:
@@ -217,7 +210,7 @@ def main():
             def run2(lane):
                 try:
                     for s in range(args.warmup + lane, n_steps_total, 2):
-                        both[lane].search(q_steps[s], term_steps[s], syn.NOW_TICKS, k, candidate_limit=n_total)
+                        both[lane].search(q_steps[s], term_steps[s], gen.NOW_TICKS, k, candidate_limit=leg.n_total)
                 except Exception as exc:         # e.g. no room for a second set of workspaces
                     errors.append(repr(exc))
 
@@ -231,18 +224,19 @@ def main():
                     t.join()
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
-            overlap = {"steps_in_flight": 2, "value": args.steps * B_local / dt2, "unit": "queries/s",
-                       "ms_per_step": 1e3 * dt2 / args.steps} if not errors else {"steps_in_flight": 2, "error": errors[0]}
+            two = ({"steps_in_flight": 2, "value": args.steps * B / dt2, "unit": "queries/s", "ms_per_step": 1e3 * dt2 / args.steps}
+                   if not errors else {"steps_in_flight": 2, "error": errors[0]})
         except Exception as exc:
-            overlap = {"steps_in_flight": 2, "error": repr(exc)}
+            two = {"steps_in_flight": 2, "error": repr(exc)}
         finally:
             if lane2 is not None:
                 lane2.close()
 
-    # sanity inside the bench: the planted row of the last step must be rank 1
-    planted = syn.planted_rows(((n_steps_total - 1) * world + rank) * B_local, B_local, n_total)
+    # sanity inside the bench: the planted row of every query of the last step must be rank 1
+    planted = gen.planted_rows((n_steps_total - 1) * B, B, leg.n_total)
     ok = [int(r) for r in last[0][:, 0]] == planted
-
+    if not getattr(gen, "PLANTED_WINS", True):        # clustered corpus: a newer row of the cluster may legitimately outrank it
+        ok = True
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,103 +244,302 @@ def main():
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
+    queries = args.steps * B
+    res = {
+        "workload": leg.workload, "value": queries / elapsed, "unit": "queries/s", "ms_per_step": 1e3 * elapsed / args.steps,
+        "queries_per_step": B, "corpus_rows": leg.n_total, "row_scores_per_sec": queries * leg.n_total / elapsed,
+        "rank1_is_planted_row": ok if getattr(gen, "PLANTED_WINS", True) else None,
+        "query_tokenisation_ms_per_step": 1e3 * tok_s / max(1, n_steps_total),
+        "query_tokenisation": "host half of KeywordScore (split / lower / distinct / stop words, then packed into the ABI arrays) "
+                              "done before the timed region; its cost per step is this field",
+        "roofline": roofline_of(stats, leg.rows_per_gpu, dim, B),
+        "search_stats": sstats,
+        "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for n, v in stats.items()},
+    }
+    if two is not None:
+        res["two_steps_in_flight"] = two
+    return res
+
+
+def _committed_traffic(kernel, rows, dim, B):
+    """HBM bytes per launch from this round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), only where the shape matches."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        for e in doc.get("entries", []):
+            if e.get("kernel") == kernel and e.get("rows") == rows and e.get("dim") == dim and e.get("batch") == B:
+                return e.get("hbm_bytes_per_launch_corrected"), "profiles/r02_pmc_hbm_traffic.json (" + e.get("command", "") + ")"
+    except Exception:
+        pass
+    return None, None
+
+
+def roofline_of(stats, rows, dim, B):
+    """The dominant kernel of the leg against its roofline.  `achieved` is priced on the bytes / operations the kernel
+    really performs (it streams the int8 shadow: N*D bytes); `frac_survey_8d` prices the same launch on SURVEY.md
+    §8(d)'s fp32 figure 4*N*D, which this kernel does not read -- a value > 1 there says exactly that."""
+    def avg(name):
+        v = stats.get(name)
+        return (v["total_ms"] / v["launches"], v["algo_bytes"] / v["launches"]) if v and v["launches"] else None
+    survey_bytes = 4.0 * rows * dim + 4.0 * B * dim + 16.0 * rows + 16.0 * B * 10
+    for name in ("screen_gemv_i8", "screen_gemv_bf16", "dot_exact"):
+        a = avg(name)
+        if a:
+            ms, bytes_per_launch = a
+            achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+            traffic, src = _committed_traffic(name, rows, dim, B)
+            return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": ms,
+                    "algo_bytes_per_launch": bytes_per_launch,
+                    "basis": "bytes this kernel streams per launch (int8 shadow N*D + 12*N row constants + queries; fp32 4*N*D for dot_exact)",
+                    "frac_survey_8d": survey_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "survey_8d_bytes_per_launch": survey_bytes}
+    for name in ("screen_i8_fused", "screen_bf16_fused"):
+        a = avg(name)
+        if a:
+            ms, bytes_per_launch = a
+            i8 = name == "screen_i8_fused"
+            ops = 2.0 * B * rows * dim
+            mfma_peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TFLOPS
+            crossover = I8_CROSSOVER_B if i8 else I8_CROSSOVER_B / 2.0 * (MFMA_BF16_PEAK_TFLOPS / MFMA_I8_PEAK_TOPS) * 2.0
+            gbs = bytes_per_launch / (ms * 1e-3) / 1e9
+            tops = ops / (ms * 1e-3) / 1e12
+            traffic, src = _committed_traffic(name, rows, dim, B)
+            hbm_bound = B < crossover
+            r = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+                 "achieved": gbs if hbm_bound else tops, "peak": HBM_PEAK_GBS if hbm_bound else mfma_peak,
+                 "unit": "GB/s" if hbm_bound else ("TOP/s" if i8 else "TFLOP/s"),
+                 "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tops / mfma_peak),
+                 "traffic": traffic, "traffic_source": src, "avg_launch_ms": ms,
+                 "algo_bytes_per_launch": bytes_per_launch, "algo_ops_per_launch": ops,
+                 "basis": ("rows of the %s shadow streamed once per launch (N*D%s bytes) + the query image; bound chosen from the batch "
+                           "against the dtype's crossover (%.0f queries)" % ("int8" if i8 else "bf16", "" if i8 else "*2", crossover)),
+                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+                 "mfma": {"achieved": tops, "peak": mfma_peak, "unit": "TOP/s" if i8 else "TFLOP/s", "frac": tops / mfma_peak},
+                 "frac_survey_8d": survey_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "survey_8d_bytes_per_launch": survey_bytes}
+            return r
+    return None
+
+
+def oracle_leg(args, env, idx, gen, n_total, B_headline, probe):
+    """cpu_baseline + parity: the C oracle (kind "port", reference arithmetic) over a candidate_limit prefix of the
+    HEADLINE corpus, timed on the host cores, and the HIP path's answers for the same queries over the same prefix
+    compared with it: rank identity and max |score delta|."""
+    import numpy as np
+    from oracle import oracle_py as orc           # checker / baseline only
+    P, torch, dev = env["P"], env["torch"], env["dev"]
+    m = min(args.cpu_sample_rows, n_total)
+    nq = min(args.cpu_sample_queries, B_headline)
+    threads = max(1, min(probe.get("cpus_in_affinity_mask") or probe["os_cpu_count"] or 1, 64))
+    emb = torch.cat([gen.embeddings(r0, min(32768, m - r0), args.dim, dev).cpu() for r0 in range(0, m, 32768)]).numpy()
+    created = gen.created_ticks(0, m, n_total, dev).cpu().numpy()
+    pool, off = gen.contents(0, m, dev)
+    corpus = orc.OracleCorpus(emb, created, (pool.cpu().numpy(), off.cpu().numpy()))
+    # the HIP path: ONE batch of B_headline queries (the headline's batch size) over the prefix; the first nq are checked
+    q = gen.query_vectors(0, B_headline, args.dim, n_total, dev)
+    texts = gen.query_texts(0, B_headline, n_total)
+    terms = [P.text.query_terms(t) for t in texts]
+    torch.cuda.synchronize()
+    g_rows, g_scores, g_counts = idx.search(q, terms, gen.NOW_TICKS, args.topk, candidate_limit=m)
+    qs = q[:nq].cpu().numpy()
+    rank_identical, max_delta, checked = True, 0.0, 0
+    t0 = time.perf_counter()
+    oracle_out = [corpus.search(qs[b], texts[b], gen.NOW_TICKS, args.topk, candidate_limit=m, threads=threads) for b in range(nq)]
+    dt = time.perf_counter() - t0
+    for b, (orow, osc, ornd) in enumerate(oracle_out):
+        kk = int(g_counts[b])
+        if kk != len(orow) or list(g_rows[b, :kk]) != list(orow):
+            rank_identical = False
+            continue
+        checked += kk
+        d = np.abs(g_scores[b, :kk] - osc)
+        max_delta = max(max_delta, float(d.max()) if kk else 0.0)
+    t1 = time.perf_counter()
+    corpus.search(qs[0], texts[0], gen.NOW_TICKS, args.topk, candidate_limit=m, threads=1)
+    dt1 = time.perf_counter() - t1
+    rows_per_s = m * nq / dt
+    # SURVEY 8(d): an optimised CPU variant beside the reference-faithful one, labelled as such -- cosine part only,
+    # fp32 BLAS GEMM over the same sample with precomputed norms (NOT the reference arithmetic), top-k by partition
+    norms = np.concatenate([np.sqrt(np.square(emb[i:i + 8192], dtype=np.float64).sum(axis=1)) for i in range(0, m, 8192)]).astype(np.float32)
+    qn = np.sqrt(np.square(qs, dtype=np.float64).sum(axis=1)).astype(np.float32)
+    t2 = time.perf_counter()
+    cos = (emb @ qs.T) / (norms[:, None] * qn[None, :] + np.float32(1e-30))
+    top = np.argpartition(-cos, args.topk, axis=0)[: args.topk]
+    dt2 = time.perf_counter() - t2
+    del cos, top
+    cpu = {
+        "value": rows_per_s / n_total, "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": f"{nq} queries x the newest {m} of {n_total} rows x {args.dim}-d scored by the C oracle (reference arithmetic, "
+                  f"full hybrid, candidate_limit = {m}) on {threads} threads in {dt:.2f}s; value = row-rate / rows per query of the "
+                  f"headline corpus (linear extrapolation in rows)",
+        "os_cpu_count": probe["os_cpu_count"], "cpus_in_affinity_mask": probe.get("cpus_in_affinity_mask"),
+        "threads_used": threads, "parallel_speedup_over_one_thread": (m * nq / dt) / (m / dt1),
+        "single_thread_value": (m / dt1) / n_total,
+        "dotnet": probe["dotnet"],
+        "csharp_reference": ("C# runtime unavailable on this box (`dotnet --version` failed): the baseline is the C restatement "
+                             "of RecallSearchService.cs, not the .NET build") if probe["dotnet"] == "unavailable"
+        else "dotnet present; the reference itself is not shipped to this box (it cannot travel), baseline stays the C restatement",
+        "optimised_variant": {"value": (m * nq / dt2) / n_total, "unit": "queries/s",
+                              "what": "cosine part only: fp32 BLAS GEMM with precomputed norms + argpartition (numpy), "
+                                      "not the reference arithmetic, no keyword or recency term"},
+    }
+    parity = {"rank_identical": rank_identical, "max_abs_score_delta": max_delta, "rows_checked": checked,
+              "queries_checked": nq, "candidate_limit": m,
+              "what": f"orr_search_batch with {B_headline} queries over the newest {m} rows of the headline corpus "
+                      f"(same kernels as the timed steps) against the oracle's ranked row ids and unrounded fp64 scores for the first {nq}"}
+    return cpu, parity
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        spawn_ranks(args, argv)                    # never returns
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    probe = host_probe() if rank == 0 else {}      # child processes only; before the first GPU call of this process
+    t_start = time.perf_counter()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    P = graft.load_package()
+    syn = importlib.import_module(graft.PKG_NAME + ".synthetic")
+    sharded = importlib.import_module(graft.PKG_NAME + ".sharded")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    env = {"P": P, "torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank}
+
+    dim, k = args.dim, args.topk
+    legs_out = {}
+    setup_s = {}
+    if world == 1:
+        rows = args.rows_per_gpu or 10_000_000
+        B = args.batch or 256
+        # ---- leg: C2 (configs[1]) on its own 1M-row shard
+        if not args.no_legs:
+            t0 = time.perf_counter()
+            idx2 = build_shard(P, syn, torch, 0, 1_000_000, dim, 1_000_000, dev, args.set_option)
+            setup_s["c2_corpus"] = time.perf_counter() - t0
+            leg = Leg("c2", workload_label(1_000_000, dim, 1, k, True, 1), 1_000_000, 1_000_000, 1)
+            legs_out["C2_1M_rows_1_query"] = run_leg(leg, args, env, idx2, None, syn, overlap=not args.no_overlap_leg)
+            idx2.close()
+            del idx2
+        if args.clustered_leg:
+            cl = importlib.import_module(graft.PKG_NAME + ".synthetic_clustered")
+            t0 = time.perf_counter()
+            idxc = build_shard(P, cl, torch, 0, 1_000_000, dim, 1_000_000, dev, args.set_option)
+            setup_s["clustered_corpus"] = time.perf_counter() - t0
+            for bq in (1, 256):
+                leg = Leg("clustered", "clustered corpus (64 centroids + 0.1 noise): " + workload_label(1_000_000, dim, bq, k, True, 1),
+                          1_000_000, 1_000_000, bq)
+                legs_out[f"clustered_1M_rows_{bq}_queries"] = run_leg(leg, args, env, idxc, None, cl)
+            idxc.close()
+            del idxc
+        torch.cuda.empty_cache()
+        # ---- headline: C3 (configs[2])
+        t0 = time.perf_counter()
+        idx = build_shard(P, syn, torch, 0, rows, dim, rows, dev, args.set_option)
+        setup_s["headline_corpus"] = time.perf_counter() - t0
+        head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, 1), rows, rows, B, terms=not args.no_terms)
+        head = run_leg(head_leg, args, env, idx, None, syn)
+        n_total, front = rows, None
+    else:
+        rows = args.rows_per_gpu or 12_500_000
+        B = args.batch or 1024
+        n_total = rows * world
+        t0 = time.perf_counter()
+        idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
+        setup_s["headline_corpus"] = time.perf_counter() - t0
+        front = sharded.ShardedRecallSearch(idx, dim, dev)
+        ranks_seen = front.rccl_ranks_seen()
+        head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, world), rows, n_total, B, terms=not args.no_terms)
+        head = run_leg(head_leg, args, env, idx, front, syn)
+        head["rccl_ranks_seen"] = ranks_seen
+        head["collectives_per_step"] = front.collectives / max(1, args.warmup + args.steps)
+        if not args.no_legs:
+            for bq in (1, 256):
+                leg = Leg(f"c4_b{bq}", workload_label(rows, dim, bq, k, False, world), rows, n_total, bq, terms=False)
+                legs_out[f"C4_cosine_only_{bq}_queries"] = run_leg(leg, args, env, idx, front, syn)
+
+    cpu = parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        cpu, parity = oracle_leg(args, env, idx, syn, n_total, B, probe)
+        setup_s["oracle_leg"] = time.perf_counter() - t0
 
     if rank == 0:
-        queries = args.steps * world * B_local
-        dom = stats.get("dot_exact", {"launches": 0, "total_ms": 0.0, "algo_bytes": 0.0})
-        roofline = None
-        # HBM bytes per dot_exact launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload shape.
-        traffic = None
-        traffic_gemv = None
-        traffic_i8 = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc_path) and (rows, dim, B_local) == (1_000_000, 3072, 1):
-            with open(pmc_path) as f:
-                for kname, kv in json.load(f)["kernels"].items():
-                    if kname == "orr::dot_exact_tiled<1, false, true, true>" and "hbm_bytes_per_launch_corrected" in kv:
-                        traffic = kv["hbm_bytes_per_launch_corrected"]
-                    if kname.startswith("orr::screen_gemv_bf16_kernel<1>") and "hbm_bytes_per_launch_corrected" in kv:
-                        traffic_gemv = kv["hbm_bytes_per_launch_corrected"]
-                    if kname.startswith("orr::screen_gemv_i8_kernel<1, false>") and "hbm_bytes_per_launch_corrected" in kv:
-                        traffic_i8 = kv["hbm_bytes_per_launch_corrected"]
-        stream_name = "screen_gemv_i8" if stats.get("screen_gemv_i8", {}).get("launches") else "screen_gemv_bf16"
-        if stream_name in stats and stats[stream_name]["launches"]:
-            # 1..8 queries per step: the dominant kernel streams a shadow of the rows -- int8 (N*D + 12*N bytes, 1..4
-            # queries) or bf16 (2*N*D bytes); survivors are re-scored from the fp32 master
-            sg = stats[stream_name]
-            avg_ms = sg["total_ms"] / sg["launches"]
-            bytes_per_launch = sg["algo_bytes"] / sg["launches"]
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": stream_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_gemv if stream_name == "screen_gemv_bf16" else traffic_i8,
-                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)",
-                        "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
-            if roofline["traffic"] is None:
-                roofline["traffic_source"] = None
-        elif dom["launches"]:
-            avg_ms = dom["total_ms"] / dom["launches"]
-            bytes_per_launch = dom["algo_bytes"] / dom["launches"]
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "dot_exact", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
-                        "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
-        elif any(stats.get(k, {}).get("launches") for k in ("screen_i8_fused", "screen_bf16_fused")):
-            # batched runs (--batch > 8): the dominant kernel is the screening GEMM of the two-stage pass, 2*B*N*D
-            # multiply-adds per launch against the dense MFMA peak of its type (MI355X_MICROARCH.md): int8 on the
-            # int8 shadow (5 POP/s), bf16 otherwise (2.5 PFLOP/s)
-            gname = "screen_i8_fused" if stats.get("screen_i8_fused", {}).get("launches") else "screen_bf16_fused"
-            sc = stats[gname]
-            avg_ms = sc["total_ms"] / sc["launches"]
-            if world * B_local <= 128:
-                # up to 128 queries fill at most half a query tile: the kernel multiplies only the live query tiles
-                # and is bound by streaming the shadow once (N*D bytes of int8 rows, 2*N*D of bf16 ones)
-                bytes_per_launch = sc["algo_bytes"] / sc["launches"]
-                achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-                traffic_live = None
-                if os.path.exists(pmc_path) and (rows, dim) == (1_000_000, 3072) and world * B_local <= 32 and gname == "screen_i8_fused":
-                    with open(pmc_path) as f:     # measured with --batch 32 (one live query tile), committed with the profiles
-                        traffic_live = json.load(f)["kernels"].get("orr::screen_bf16_kernel<true, 0, true, 1> (bench.py --batch 32)", {}) \
-                            .get("hbm_bytes_per_launch_corrected")
-                roofline = {"bound": "hbm", "kernel": gname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_live,
-                            "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic_live else None,
-                            "avg_launch_ms": avg_ms, "algo_bytes_per_launch": bytes_per_launch}
-            else:
-                flops = 2.0 * (world * B_local) * rows * dim
-                achieved = flops / (avg_ms * 1e-3) / 1e12
-                peak = MFMA_I8_PEAK_TOPS if gname == "screen_i8_fused" else MFMA_BF16_PEAK_TFLOPS
-                roofline = {"bound": "mfma", "kernel": gname, "achieved": achieved, "peak": peak,
-                            "unit": "TOP/s" if gname == "screen_i8_fused" else "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                            "avg_launch_ms": avg_ms, "algo_flops_per_launch": flops}
+        cfg_name = config_name(rows, dim, B, world, not args.no_terms)
         out = {
-            "metric": "queries/sec at top-k=10 over N x 3072-d chunks",
-            "value": queries / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 products summed in f64 (reference arithmetic)",
+            "metric": "queries/sec at top-k=10 over N x 3072-d chunks; score delta vs C# reference (oracle) in `parity`",
+            "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8 screen (bounded, all rows) + f32 x f32 -> f64 exact re-score of the survivors (reference arithmetic)",
             "data": "synthetic",
-            "config": {"workload": f"C2: {rows} chunks x {dim}-d fp32 per GPU, {B_local} query per GPU per step, "
-                                   f"top-k={k}, full hybrid (cosine+keyword+recency), candidate_limit=corpus",
-                       "corpus_rows": n_total, "queries_per_step": world * B_local, "options": args.set_option,
-                       "steps_in_flight": n_lanes,
-                       "parallelism": f"row-sharded x{world}, all-gather of per-shard top-k'" if world > 1 else "single GPU"},
-            "row_scores_per_sec": queries * n_total / elapsed,
-            "two_steps_in_flight": overlap,
-            "rank1_is_planted_row": ok,
-            "roofline": roofline,
-            "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])}
-                        for n, v in stats.items()},
+            "config": {"workload": head["workload"], "name": cfg_name, "corpus_rows": n_total, "rows_per_gpu": rows,
+                       "queries_per_step": B, "options": args.set_option, "steps_in_flight": 1,
+                       "parallelism": (f"row-sharded x{world}: broadcast of the batch from rank 0, one all-gather of per-shard top-k' "
+                                       f"records (RCCL), host merge on every rank") if world > 1 else "single GPU"},
+            "row_scores_per_sec": head["row_scores_per_sec"],
+            "rank1_is_planted_row": head["rank1_is_planted_row"],
+            "roofline": head["roofline"],
+            "search_stats": head["search_stats"],
+            "kernels": head["kernels"],
+            "query_tokenisation_ms_per_step": head["query_tokenisation_ms_per_step"],
+            "query_tokenisation": head["query_tokenisation"],
+            "legs": legs_out,
+            "peaks": {"hbm_gbs": HBM_PEAK_GBS, "mfma_i8_tops_dense": MFMA_I8_PEAK_TOPS, "mfma_bf16_tflops_dense": MFMA_BF16_PEAK_TFLOPS,
+                      "source": "MI355X_MICROARCH.md chip-level parameters (spec, dense)", "read_on_this_box": probe.get("gpu")},
+            "setup_s": {kk: round(v, 2) for kk, v in setup_s.items()},
+            "total_s": round(time.perf_counter() - t_start, 2),
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, syn, args, n_total, torch, dev)
+        for extra in ("rccl_ranks_seen", "collectives_per_step"):
+            if extra in head:
+                out[extra] = head[extra]
+        if parity is not None:
+            out["parity"] = parity
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        elif world == 1:
+            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for ln in lanes[1:]:
-        ln.close()
     idx.close()
+
+
+def config_name(rows, dim, B, world, terms):
+    if dim == 3072 and world == 1 and rows == 1_000_000 and B == 1:
+        return "C2"
+    if dim == 3072 and world == 1 and rows == 10_000_000 and B == 256:
+        return "C3"
+    if dim == 3072 and world == 8 and rows == 12_500_000:
+        return "C5" if terms and B == 1024 else ("C4" if not terms and B in (1, 256) else "C4/C5 shape, other batch")
+    if dim == 3072 and rows == 12_500_000:
+        return f"C4/C5 per-GPU shape on {world} GPU(s)"
+    return "custom"
+
+
+def workload_label(rows, dim, B, k, terms, world):
+    name = config_name(rows, dim, B, world, terms)
+    total = rows * world
+    return (f"{name}: {total} chunks x {dim}-d fp32" + (f" row-sharded over {world} GPUs ({rows} per GPU)" if world > 1 else " on one GPU")
+            + f", batch={B} queries per step, top-k={k}, "
+            + ("full hybrid (cosine+keyword+recency)" if terms else "cosine + recency only (no query terms)")
+            + ", candidate_limit=corpus")
 
 
 if __name__ == "__main__":

@@ -23,7 +23,9 @@
  *     the opaque handle.  Strings cross as UTF-8 bytes with explicit offsets;
  *     nothing relies on NUL termination; nothing is freed across the ABI.
  *   - pointers marked "host or device" may be either; the library copies with
- *     hipMemcpyDefault.
+ *     hipMemcpyDefault.  The library works on its own non-blocking HIP streams: device-resident
+ *     inputs must be COMPLETE (their producing stream synchronised, or an event waited for)
+ *     before the call, and device-resident outputs are complete when the call returns.
  *   - threads: searches on a sealed index may be issued from any thread (they
  *     are serialised per index in this version); append / seal are exclusive.
  */
@@ -92,6 +94,23 @@ typedef struct orr_kernel_stat {
     double  total_ms;        /* sum of hipEventElapsedTime over those launches                 */
     double  algo_bytes;      /* algorithmic bytes summed over those launches       */
 } orr_kernel_stat;
+
+/* Counters of one index since the last reset (orr_index_search_stats): how often the cheap passes had to be
+ * repeated, and what the screening pass of the two-stage search kept.  128 bytes. */
+typedef struct orr_search_stats {
+    int64_t searches;            /* orr_search_batch calls                                                    */
+    int64_t queries;             /* queries in them                                                           */
+    int64_t passes;              /* device passes run for them (= searches when nothing had to be repeated)   */
+    int64_t requeried;           /* queries that went through another pass (summed over repeats)              */
+    int64_t overflowed_queries;  /* queries whose survivors did not fit their buffer in some pass             */
+    int64_t buffer_growths;      /* times the survivors' buffers were enlarged from the measured counts       */
+    int64_t exact_pass_queries;  /* queries that ended in the reference-arithmetic pass over every row        */
+    int64_t survivors_total;     /* (query,row) pairs kept by the screening pass, summed over queries         */
+    int64_t survivor_samples;    /* queries counted in survivors_total                                        */
+    int64_t survivors_max;       /* largest count of one query                                                */
+    int64_t survivor_capacity;   /* buffer entries per query the index uses now                               */
+    int64_t reserved[5];
+} orr_search_stats;
 
 int         orr_abi_version(void);
 int         orr_device_count(void);                 /* gfx950 devices visible; 0 if none        */
@@ -240,6 +259,8 @@ int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q
 /* ---- measurement ---------------------------------------------------------*/
 int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets the counters */
 int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap);  /* returns count */
+
+int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset);  /* out may be NULL (reset only) */
 
 #ifdef __cplusplus
 }

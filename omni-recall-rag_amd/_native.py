@@ -41,6 +41,12 @@ class OrrKernelStat(C.Structure):
                 ("algo_bytes", C.c_double)]
 
 
+class OrrSearchStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("searches", "queries", "passes", "requeried", "overflowed_queries", "buffer_growths",
+                                         "exact_pass_queries", "survivors_total", "survivor_samples", "survivors_max",
+                                         "survivor_capacity")] + [("reserved", C.c_int64 * 5)]
+
+
 def _load(path: str) -> C.CDLL:
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
@@ -94,6 +100,8 @@ hip.orr_index_set_profiling.restype = C.c_int
 hip.orr_index_set_profiling.argtypes = [_vp, _i32]
 hip.orr_index_kernel_stats.restype = C.c_int
 hip.orr_index_kernel_stats.argtypes = [_vp, _vp, _i32]
+hip.orr_index_search_stats.restype = C.c_int
+hip.orr_index_search_stats.argtypes = [_vp, C.POINTER(OrrSearchStats), _i32]
 
 host.orrh_is_blank.restype = _i32
 host.orrh_is_blank.argtypes = [C.c_char_p, _i64]
@@ -160,7 +168,7 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
     "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
     "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_view",
-    "orr_index_delete_rows", "orr_index_live_rows",
+    "orr_index_delete_rows", "orr_index_live_rows", "orr_index_search_stats",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",

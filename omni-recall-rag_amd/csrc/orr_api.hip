@@ -164,10 +164,15 @@ struct orr_index {
     std::vector<uint32_t> h_clen;      // host mirror of content lengths
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     std::vector<double> h_norm_a;      // exact query norms of the batch in flight (run_shard -> host finish)
+    std::vector<uint32_t> h_survivors; // two-stage pass: (query,row) pairs the screen kept, per query of the batch in flight (else empty)
+    uint32_t survivor_cap = 8192;      // entries per query of the survivors' buffers; grows when a query overflows it (clustered corpora)
+    uint32_t pass_cap = 8192;          // what the pass in flight uses: survivor_cap, halved until a batch's buffers stay below 2 GiB
+    orr_search_stats sstats{};         // orr_index_search_stats
     bool sealed = false;
     bool is_view = false;              // a second search lane over another index's sealed corpus (orr_index_view)
     bool opt_fuse_epilogue = false;
     int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
+    int opt_shard_pass = 0;            // orr_search_shard: 0 the library picks the pass, 1 unfused batched pass, 2 exact pass
     DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
     bool shadow_ready = false, shadow_failed = false;
     DevBuf emb_i8, i8_scale, i8_rel_err, i8_rel_hat, i8_rowf;   // int8 shadow: streaming screen of 1..4 queries (K2i), screening GEMM (K2j)
@@ -181,11 +186,11 @@ struct orr_index {
 
     // search workspace
     DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero, ws_norm_a;
-    DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start;
+    DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start, ws_qsub;
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     size_t bitmaps_clean = 0;          // leading bytes of ws_bitmaps known to be zero (cleared again behind every search)
     const void *bitmaps_clean_of = nullptr;
-    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm;
+    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm, pin_cnt;
     hipEvent_t ev_q = nullptr;
 
     // profiling
@@ -547,12 +552,12 @@ void orr_index_destroy(orr_index *idx)
     idx->ws_norm_a.release();
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
-                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start,
+                      &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start, &idx->ws_qsub,
                       &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
     idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
-    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release(); idx->pin_norm.release();
+    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release(); idx->pin_norm.release(); idx->pin_cnt.release();
     if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
@@ -1065,6 +1070,11 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
         idx->dead_before = value;
         return ORR_OK;
     }
+    if (strcmp(name, "shard_pass") == 0) {
+        if (value < 0 || value > 2) return fail(ORR_EINVAL, "orr_index_set_option: shard_pass takes 0, 1 or 2");
+        idx->opt_shard_pass = (int)value;
+        return ORR_OK;
+    }
     if (strcmp(name, "two_stage") == 0) {
         if (value < 0 || value > 2) return fail(ORR_EINVAL, "orr_index_set_option: two_stage takes 0, 1 or 2");
         idx->opt_two_stage = (int)value;
@@ -1191,6 +1201,7 @@ struct BatchArgs {
     bool no_fuse = false;          // keep the batched pass unfused (retry after a candidate-buffer overflow)
     orr_candidate *out_dev = nullptr;   // orr_search_shard with a device-resident `out`: the kernels write the records there
     mutable bool used_fused = false;
+    mutable bool used_two_stage = false;   // the pass kept survivors in per-query buffers (idx->h_survivors holds their counts)
 };
 
 const orr_index *owner_of(const orr_index *idx) { return idx->parent ? idx->parent : idx; }
@@ -1325,6 +1336,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     const bool approx_pass = use_mfma;                   // records carry no dot yet: filled in exactly on the device
     a.used_mfma = approx_pass;
     a.used_fused = false;
+    a.used_two_stage = false;
+    idx->h_survivors.clear();
     const bool direct_host = host_records && !approx_pass && rec_bytes <= (256u << 10);
     orr_candidate *d_cand = nullptr;
     if (direct_host) {
@@ -1679,7 +1692,9 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             // ---- fused batched pass: prefix lists -> floor keys -> GEMM with the scoring epilogue ->
             // survivors' buffers -> lists; the final merge reads prefix lists + buffer lists
             a.used_fused = true;
-            constexpr uint32_t kCap = 8192;                                 // survivors kept per query
+            uint32_t kCap = idx->survivor_cap;                              // survivors kept per query (a multiple of 64)
+            while (kCap > 8192 && (size_t)B * kCap * 40 > ((size_t)2 << 30)) kCap >>= 1;
+            idx->pass_cap = kCap;
             const int32_t buf_lists = (int32_t)(kCap / orr::kSelWidth);
             const int32_t lists_total = fused_sample_seg + buf_lists;
             ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)lists_total * orr::kSelWidth));
@@ -1830,6 +1845,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                                 d_cand, s));
                     records_have_dots = true;
                 }
+                // the survivors' counts go back with the records: per-query escalation and orr_index_search_stats
+                ORR_TRY(idx->pin_cnt.reserve(sizeof(uint32_t) * (size_t)B));
+                HIP_TRY(hipMemcpyAsync(idx->pin_cnt.p, epi.cnt, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+                a.used_two_stage = true;
             } else {
             {
                 Timed t(idx, "select_floor", 0.0);
@@ -1932,6 +1951,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         idx->bitmaps_clean = std::max(bm_bytes, bm_clean_before);
     }
     if (dev_norms) memcpy(idx->h_norm_a.data(), idx->pin_norm.p, sizeof(double) * (size_t)B);
+    if (a.used_two_stage) idx->h_survivors.assign(idx->pin_cnt.as<uint32_t>(), idx->pin_cnt.as<uint32_t>() + B);
     g_ht.mark(4);
     collect_events(idx);
     if (kw_overflow_possible) {
@@ -2015,7 +2035,8 @@ int32_t finish_query(const orr_candidate *const *shard_recs, int32_t n_shards, i
 
 int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all, int32_t dim, bool use_cos,
                const float *q_host, const double *norms, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
-               int64_t *out_rows, double *out_scores, int32_t *out_counts, int32_t *out_uncertified)
+               int64_t *out_rows, double *out_scores, int32_t *out_counts, int32_t *out_uncertified,
+               uint8_t *out_certified = nullptr)
 {
     const int32_t take = std::max<int32_t>(1, topk);
     int32_t unc = 0;
@@ -2040,6 +2061,7 @@ int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate 
                                              out_rows + (size_t)b * take, out_scores + (size_t)b * take, &cert, &err);
             if (err != ORR_OK) { *err_out = err; return; }
             if (out_counts) out_counts[b] = cnt;
+            if (out_certified) out_certified[b] = cert ? 1 : 0;
             if (!cert) ++*unc_out;
         }
     };
@@ -2064,9 +2086,173 @@ int merge_impl(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate 
     return ORR_OK;
 }
 
+
+// ---- one batch through the passes, escalating ONLY the queries that could not be certified ----------------------------
+// A query whose top-k could not be certified (a tie at the cut, a survivors' buffer that overflowed, k' too small for a
+// mass of equal scores) goes through the next more exact pass as part of a compacted sub-batch; the others keep their
+// results.  Order of escalation: larger survivors' buffers (when that was the only problem and they stay affordable) ->
+// unfused batched pass -> the reference-arithmetic pass over all rows -> k' x 4.  Passes whose workspace grows with
+// (queries x rows) are run over slices of the sub-batch, so the workspace stays bounded (kPassWorkspaceBytes).
+constexpr size_t kPassWorkspaceBytes = (size_t)4 << 30;
+
+struct SubBatch {                  // storage of a compacted sub-batch (the vectors live in idx->ws_qsub when they are device-resident)
+    std::vector<float> q_host;
+    std::vector<uint8_t> pool;
+    std::vector<uint32_t> term_off, qoff;
+};
+
+int build_subset(orr_index *idx, const BatchArgs &orig, const std::vector<int32_t> &ids, SubBatch &sb, BatchArgs &out)
+{
+    out = orig;
+    const int32_t nb = (int32_t)ids.size();
+    out.B = nb;
+    out.used_mfma = out.used_fused = out.used_two_stage = false;
+    if (orig.dim > 0) {
+        const size_t row = (size_t)orig.dim;
+        if (is_device_pointer(orig.q)) {
+            ORR_TRY(idx->ws_qsub.reserve(sizeof(float) * row * (size_t)nb));
+            for (int32_t i = 0; i < nb; ++i)
+                HIP_TRY(hipMemcpyAsync(idx->ws_qsub.as<float>() + (size_t)i * row, orig.q + (size_t)ids[(size_t)i] * row, sizeof(float) * row,
+                                       hipMemcpyDeviceToDevice, idx->stream));
+            HIP_TRY(hipStreamSynchronize(idx->stream));
+            out.q = idx->ws_qsub.as<float>();
+        } else {
+            sb.q_host.resize(row * (size_t)nb);
+            for (int32_t i = 0; i < nb; ++i)
+                memcpy(sb.q_host.data() + (size_t)i * row, orig.q + (size_t)ids[(size_t)i] * row, sizeof(float) * row);
+            out.q = sb.q_host.data();
+        }
+    }
+    sb.pool.clear(); sb.term_off.assign(1, 0u); sb.qoff.assign(1, 0u);
+    for (int32_t i = 0; i < nb; ++i) {
+        const int32_t b = ids[(size_t)i];
+        for (uint32_t t = orig.query_term_off[b]; t < orig.query_term_off[b + 1]; ++t) {
+            const uint32_t o = orig.term_off[t], e = orig.term_off[t + 1];
+            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t);
+            sb.pool.insert(sb.pool.end(), orig.terms_utf8 + o, orig.terms_utf8 + e);
+            sb.term_off.push_back((uint32_t)sb.pool.size());
+        }
+        sb.qoff.push_back((uint32_t)sb.term_off.size() - 1u);
+    }
+    sb.pool.push_back(0);
+    out.terms_utf8 = sb.pool.data();
+    out.term_off = sb.term_off.data();
+    out.query_term_off = sb.qoff.data();
+    return ORR_OK;
+}
+
+// ids: queries of `orig` to answer (ascending); whole = ids is the entire batch in order.  flags (no_fuse / force_exact) are
+// carried in `orig` for sub-batches.  Results are written to out_*[ids[i]].
+int search_ids(orr_index *idx, const BatchArgs &orig, const std::vector<int32_t> &ids, bool whole, int64_t kprime, int64_t n,
+               int64_t *out_rows, double *out_scores, int32_t *out_counts, int depth)
+{
+    const int32_t nb = (int32_t)ids.size();
+    const int32_t take = std::max<int32_t>(1, orig.topk);
+    const bool use_cos = orig.dim > 0 && orig.dim == idx->dim;
+    // passes that keep a number per (query,row): slices of the sub-batch
+    if ((orig.no_fuse || orig.force_exact) && nb > 1 && (size_t)nb * (size_t)std::max<int64_t>(n, 1) * 8 > kPassWorkspaceBytes) {
+        const int32_t per = (int32_t)std::max<size_t>(1, kPassWorkspaceBytes / ((size_t)std::max<int64_t>(n, 1) * 8));
+        for (int32_t i0 = 0; i0 < nb; i0 += per) {
+            std::vector<int32_t> part(ids.begin() + i0, ids.begin() + std::min<int32_t>(nb, i0 + per));
+            ORR_TRY(search_ids(idx, orig, part, false, kprime, n, out_rows, out_scores, out_counts, depth));
+        }
+        return ORR_OK;
+    }
+    SubBatch sb;
+    BatchArgs cur = orig;
+    if (!whole) ORR_TRY(build_subset(idx, orig, ids, sb, cur));
+    cur.no_fuse = orig.no_fuse; cur.force_exact = orig.force_exact;
+
+    const float *q_host = nullptr;
+    const orr_candidate *recs = nullptr;
+    ORR_TRY(run_shard(idx, cur, (int32_t)kprime, true, &q_host, &recs));
+    idx->sstats.passes += 1;
+    if (depth > 0) idx->sstats.requeried += nb;
+    std::vector<orr_candidate> copied;
+    if (!recs) {                                  // large record sets stay on the device until here
+        copied.resize((size_t)nb * ((size_t)kprime + 1));
+        HIP_TRY(hipMemcpy(copied.data(), idx->ws_cand.p, sizeof(orr_candidate) * copied.size(), hipMemcpyDeviceToHost));
+        recs = copied.data();
+    }
+    std::vector<uint8_t> cert((size_t)nb, 1);
+    int32_t unc = 0;
+    if (whole) {
+        ORR_TRY(merge_impl(1, nb, (int32_t)kprime, recs, cur.dim, use_cos, q_host, use_cos ? idx->h_norm_a.data() : nullptr,
+                           cur.query_term_off, cur.now_ticks, cur.topk, out_rows, out_scores, out_counts, &unc, cert.data()));
+    } else {
+        std::vector<int64_t> rows((size_t)nb * take);
+        std::vector<double> scores((size_t)nb * take);
+        std::vector<int32_t> counts((size_t)nb);
+        ORR_TRY(merge_impl(1, nb, (int32_t)kprime, recs, cur.dim, use_cos, q_host, use_cos ? idx->h_norm_a.data() : nullptr,
+                           cur.query_term_off, cur.now_ticks, cur.topk, rows.data(), scores.data(), counts.data(), &unc, cert.data()));
+        for (int32_t i = 0; i < nb; ++i) {
+            const size_t b = (size_t)ids[(size_t)i];
+            memcpy(out_rows + b * take, rows.data() + (size_t)i * take, sizeof(int64_t) * take);
+            memcpy(out_scores + b * take, scores.data() + (size_t)i * take, sizeof(double) * take);
+            if (out_counts) out_counts[b] = counts[(size_t)i];
+        }
+    }
+    g_ht.mark(5);
+    // survivors of the screening pass (two-stage): statistics, and the buffer size the next pass needs
+    uint32_t worst_unc_survivors = 0;
+    bool unc_only_overflow = unc > 0;
+    if (cur.used_two_stage && (int32_t)idx->h_survivors.size() == nb) {
+        for (int32_t i = 0; i < nb; ++i) {
+            const uint32_t c = idx->h_survivors[(size_t)i];
+            idx->sstats.survivors_total += c;
+            idx->sstats.survivor_samples += 1;
+            if ((int64_t)c > idx->sstats.survivors_max) idx->sstats.survivors_max = c;
+            if (c > idx->pass_cap) idx->sstats.overflowed_queries += 1;
+            if (!cert[(size_t)i]) {
+                if (c > idx->pass_cap) worst_unc_survivors = std::max(worst_unc_survivors, c);
+                else unc_only_overflow = false;
+            }
+        }
+    } else {
+        unc_only_overflow = false;
+    }
+    idx->sstats.survivor_capacity = idx->survivor_cap;
+    if (unc == 0) return ORR_OK;
+
+    std::vector<int32_t> again;
+    for (int32_t i = 0; i < nb; ++i) if (!cert[(size_t)i]) again.push_back(ids[(size_t)i]);
+    BatchArgs next = orig;
+    next.no_fuse = cur.no_fuse; next.force_exact = cur.force_exact;
+    if (unc_only_overflow && worst_unc_survivors < (1u << 19) && (int64_t)worst_unc_survivors * 2 < n &&
+        (size_t)again.size() * (size_t)worst_unc_survivors * 96 < ((size_t)2 << 30)) {
+        // the screen kept more pairs than the buffers hold (rows clustered around the query): the same pass again for
+        // these queries with buffers sized from the measured counts; the index keeps the larger size for later searches
+        uint32_t cap = idx->pass_cap;
+        while (cap < worst_unc_survivors + worst_unc_survivors / 8) cap *= 2;
+        if (cap > idx->survivor_cap) idx->survivor_cap = cap;
+        idx->sstats.buffer_growths += 1;
+    } else if (cur.used_fused && !cur.no_fuse) {
+        next.no_fuse = true;                                   // a tie at the cut or an overflow too large to buffer: unfused pass
+    } else if (cur.used_mfma) {
+        next.force_exact = true;                               // then the exact pass, same k'
+        idx->sstats.exact_pass_queries += (int64_t)again.size();
+    } else if (kprime >= n) {
+        return ORR_OK;                                         // every participating row was a candidate: nothing more exact exists
+    } else {
+        kprime = std::min<int64_t>(n, kprime * 4);
+    }
+    if (depth > 40) return fail(ORR_EDEVICE, "orr_search_batch: escalation did not terminate");
+    return search_ids(idx, next, again, false, kprime, n, out_rows, out_scores, out_counts, depth + 1);
+}
+
 }  // namespace
 
 extern "C" {
+
+int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset)
+{
+    if (!idx) return fail(ORR_EINVAL, "orr_index_search_stats: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->sstats.survivor_capacity = idx->survivor_cap;
+    if (out) *out = idx->sstats;
+    if (reset) { const int64_t cap = idx->sstats.survivor_capacity; idx->sstats = orr_search_stats{}; idx->sstats.survivor_capacity = cap; }
+    return ORR_OK;
+}
 
 int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
                      const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
@@ -2077,6 +2263,9 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
     std::lock_guard<std::mutex> lock(idx->mu);
+    // the caller's escalation after a merge that could not certify every query (orr_merge_candidates)
+    a.no_fuse = idx->opt_shard_pass >= 1;
+    a.force_exact = idx->opt_shard_pass >= 2;
     if (is_device_pointer(out)) {               // records written where the caller wants them (the all-gather's send buffer)
         a.out_dev = out;
         ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
@@ -2111,32 +2300,17 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     std::lock_guard<std::mutex> lock(idx->mu);
     const int32_t take = std::max<int32_t>(1, topk);
     const int64_t n = participating_rows(idx, candidate_limit);
-    const bool use_cos = dim > 0 && dim == idx->dim;
 
     // k': the asked k plus a margin, escalated until every query certifies.
     int64_t kprime = std::min<int64_t>(std::max<int64_t>(1, n), std::max<int64_t>((int64_t)take + 22, 32));
     if (kprime > orr::kSelWidth && take + 8 <= orr::kSelWidth) kprime = orr::kSelWidth;
-    for (;;) {
-        const float *q_host = nullptr;
-        const orr_candidate *recs = nullptr;
-        ORR_TRY(run_shard(idx, a, (int32_t)kprime, true, &q_host, &recs));
-        std::vector<orr_candidate> copied;
-        if (!recs) {                                  // large record sets stay on the device until here
-            copied.resize((size_t)B * ((size_t)kprime + 1));
-            HIP_TRY(hipMemcpy(copied.data(), idx->ws_cand.p, sizeof(orr_candidate) * copied.size(), hipMemcpyDeviceToHost));
-            recs = copied.data();
-        }
-        int32_t unc = 0;
-        ORR_TRY(merge_impl(1, B, (int32_t)kprime, recs, dim, use_cos, q_host, use_cos ? idx->h_norm_a.data() : nullptr,
-                           query_term_off, now_ticks, topk, out_rows, out_scores, out_counts, &unc));
-        g_ht.mark(5);
-        g_ht.done();
-        if (unc == 0) return ORR_OK;
-        if (a.used_fused && !a.no_fuse) { a.no_fuse = true; continue; }   // a buffer overflow or a tie at the cut: unfused pass
-        if (a.used_mfma) { a.force_exact = true; continue; }        // then the exact pass, same k'
-        if (kprime >= n) return ORR_OK;
-        kprime = std::min<int64_t>(n, kprime * 4);
-    }
+    idx->sstats.searches += 1;
+    idx->sstats.queries += B;
+    std::vector<int32_t> all((size_t)B);
+    std::iota(all.begin(), all.end(), 0);
+    const int r = search_ids(idx, a, all, true, kprime, n, out_rows, out_scores, out_counts, 0);
+    g_ht.done();
+    return r;
 }
 
 }  // extern "C"

@@ -9,75 +9,171 @@ namespace orr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 // Scoring epilogue shared by the batched kernels.  acc[i][j] are 32 x 32 accumulator tiles of
-// v_mfma_f32_32x32x16_bf16: element e of lane (fr = lane & 31, fh = lane >> 5) belongs to query
-// qbase + 32 i + (e & 3) + 8 (e >> 2) + 4 fh and to row colbase + 32 j + fr.
+// v_mfma_f32_32x32x16_bf16 / v_mfma_i32_32x32x32_i8: element e of lane (fr = lane & 31, fh = lane >> 5) belongs
+// to query qbase + 32 i + (e & 3) + 8 (e >> 2) + 4 fh and to row colbase + 32 j + fr.
 //
-// Pass 1 (straight-line, fp32): the score with the exact keyword term -- match counts come
-// bit-sliced from the count planes, one 32-bit word per (plane, 32 queries, row) -- against the
-// query's floor minus a margin.  The few elements that pass are parked in a per-thread queue in
-// LDS (the operand images are dead by now; the caller has put a workgroup barrier in between).
-// Pass 2 (one copy of the code): fp64 score from the term bitmaps, compare with the floor key,
-// atomic append to the query's buffer.  A non-finite accumulator (fp32 overflow) is never
-// filtered.  A thread whose queue is full (a "hot" tile: e.g. the newest rows pass for every query)
-// appends further elements straight to the buffers when RESCORED says that every buffer entry gets its
-// exact key afterwards anyway (two-stage pass); otherwise it bumps the query's counter past the buffer
-// capacity, which the host treats like any other overflow (the batch is repeated unfused).
-constexpr int kEpiQueue = 8;            // parked elements per thread
+// Pass 1 (fp32): an upper bound of the pair's score with the exact keyword term -- match counts (saturating at 15) come
+// from the count words, four bits per (query,row), four 32-bit words per (32 queries, row) -- against the query's floor
+// minus a margin.  The
+// few elements that pass are parked in a per-thread queue in LDS (the operand images are dead by now; the caller has
+// put a workgroup barrier in between).
+// Pass 2 (one copy of the code): fp64 score from the term bitmaps, compare with the floor key, atomic append to the
+// query's buffer.  A non-finite accumulator (fp32 overflow) is never filtered.  A thread whose queue is full (a "hot"
+// tile: e.g. the newest rows pass for every query) appends further elements straight to the buffers when RESCORED says
+// that every buffer entry gets its exact key afterwards anyway (two-stage pass); otherwise it bumps the query's counter
+// past the buffer capacity, which the host treats like any other overflow (the batch is repeated unfused).
+//
+// What the structure below is shaped by (in-kernel stamps of the int8 screening GEMM at 1M x 3072 rows x 256 queries,
+// ORR_SCREEN_STAMPS; a tile's K loop is 77,000 cycles):
+//   * with the query constants loaded from global memory inside the element loop, every element ended in a (rarely
+//     taken) branch the compiler moves no load across: 64 dependent trips to L2 per tile;
+//   * with the loads hoisted but a branch per element kept, a block of 32 queries still took 6,500 cycles (31,000 per
+//     tile): each element is a serial chain plus scalar bookkeeping plus the branch, 5.6 cycles per instruction with
+//     both waves of the SIMD running.
+// Hence: ONE global trip per tile (EpiTileLoads, issued by the caller before its barrier), the tile's query constants
+// in LDS (staged by the caller; LDS reads need no vmcnt wait and the compiler pipelines them freely), and pass 1 in
+// two forms: 1a BRANCH-FREE over a block of 32 queries, keeping only the wave-wide OR of the answers (the v_cmp
+// results OR-ed in scalar registers); 1b, the element-by-element form with the parking code, runs only for the rare
+// block in which 1a found something.
+constexpr int kEpiQueue = 7;            // parked elements per thread (7 x 8 B x 512 threads = 28 KiB: the stage's last 4 KiB hold the query constants)
+constexpr int kEpiQueueBytes = kEpiQueue * 8 * 512;
 struct EpiParked { float a; uint32_t idx; };
 
-template <int NI, int NJ, bool RESCORED>
-__device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int qbase, int64_t colbase, int32_t B,
-                                               int64_t n_rows, const FusedEpilogue &epi, int lane, EpiParked *queue,
-                                               int queue_stride, uint32_t idx_salt = 0)
+// Everything pass 1 reads from global memory for one output tile and one lane, as loaded (no arithmetic on it yet, so
+// that the loads stay in flight across the caller's barrier): the rows' constants and all their count-plane words.
+template <int NI, int NJ>
+struct EpiTileLoads {
+    double2 rc[NJ];
+    float4 rf[NJ];
+    uint32_t w[NI][NJ][kCountPlanes];
+};
+
+template <int NI, int NJ>
+__device__ __forceinline__ void epilogue_issue_loads(EpiTileLoads<NI, NJ> &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
+                                                     const FusedEpilogue &epi, int lane)
 {
+    const int fr = lane & 31;
+    const int32_t n_qg = (B + 31) >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int64_t col = colbase + j * 32 + fr;
+        const int64_t colc = col < n_rows ? col : n_rows - 1;              // clamped, never branched around
+        L.rc[j] = epi.rowc[colc];
+        L.rf[j] = epi.i8_rowf ? epi.i8_rowf[colc] : make_float4(1.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int qg = (qbase + i * 32) >> 5;
+            const int qgc = qg < n_qg ? qg : n_qg - 1;
+#pragma unroll
+            for (int p = 0; p < kCountPlanes; ++p)
+                L.w[i][j][p] = epi.count_planes ? epi.count_planes[((int64_t)p * n_qg + qgc) * epi.plane_stride + colc] : 0u;
+        }
+    }
+}
+
+// Integer accumulators (ACC = i32x16, the int8 screening GEMM) go in as they are: |I| <= 3072 * 127^2, the conversion
+// to fp32 costs at most 2^-24, inside the margin of the int8 row bound (i8_rowf.y).  A coarser gate in front of pass 1
+// (two integer thresholds per 32 x 32 block from the extremes of the block's 32 queries, v_max3_i32 over a lane's 16
+// dots) was built and measured this round: it closes for 99 % of the blocks of cosine-only batches and for none of a
+// hybrid batch (the floor sits within the keyword credit, 0.2, of the bulk), and next to the branch-free pass 1a it
+// bought 2 % in the first case and cost 2.5 % in the second; removed.
+//
+// pre / qf_lds (STAGED): the caller's pre-issued loads and the tile's query constants in LDS, indexed by
+// [query - qbase]; otherwise (orr_gemm.hip) everything is loaded here and only pass 1b runs.
+template <int NI, int NJ, bool RESCORED, typename ACC = f32x16, bool STAGED = false>
+__device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qbase, int64_t colbase, int32_t B,
+                                               int64_t n_rows, const FusedEpilogue &epi, int lane, EpiParked *queue,
+                                               int queue_stride, uint32_t idx_salt = 0, unsigned long long *st = nullptr,
+                                               const EpiTileLoads<NI, NJ> *pre = nullptr, const float4 *qf_lds = nullptr)
+{
+    constexpr bool INT_ACC = !__is_same(ACC, f32x16);
+    // st (diagnostic, ORR_SCREEN_STAMPS): s_memtime of lane 0 at the phases of this call -- [4] row constants in registers,
+    // [5] first block of 32 queries done, [6] pass 1 done (the caller stamps the end of pass 2)
+#define ORR_EPI_STAMP(k) if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime()
     // idx_salt: zero, but opaque to the compiler when the caller runs this inside a loop over output tiles -- it
     // keeps the 128 constant tags of the parked entries from being hoisted out of that loop into registers.
     const int fr = lane & 31, fh = lane >> 5;
-    float rb[NJ], rr[NJ], ea[NJ], eb[NJ];
+    EpiTileLoads<NI, NJ> own;
+    if constexpr (!STAGED) epilogue_issue_loads(own, qbase, colbase, B, n_rows, epi, lane);
+    const EpiTileLoads<NI, NJ> &L = STAGED ? *pre : own;
+    float rb[NJ], cj[NJ], eb[NJ];                                          // cj: the row's share of the bound: recency + (int8) its own quantisation error
     int64_t cols[NJ];
     bool ok[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         cols[j] = colbase + j * 32 + fr;                                   // this lane's row of E
         ok[j] = cols[j] < n_rows;
-        const double2 rc = epi.rowc[ok[j] ? cols[j] : n_rows - 1];
-        rb[j] = (float)rc.x;
-        rr[j] = ok[j] ? (float)rc.y : -__builtin_huge_valf();              // rows past the end never pass
-        ea[j] = 0.f; eb[j] = 0.f;
+        rb[j] = (float)L.rc[j].x;
+        const float rr = ok[j] ? (float)L.rc[j].y : -__builtin_huge_valf();   // rows past the end never pass
+        float ea = 0.f;
+        eb[j] = 0.f;
         if (epi.i8_rowf) {                                                 // int8 GEMM: acc is the integer dot
-            const float4 rf = epi.i8_rowf[ok[j] ? cols[j] : n_rows - 1];
-            rb[j] *= rf.x;
-            ea[j] = rf.y; eb[j] = rf.z;
+            rb[j] *= L.rf[j].x;
+            ea = L.rf[j].y; eb[j] = L.rf[j].z;
         }
+        cj[j] = rr + ea;
     }
-    const int32_t n_qg = (B + 31) >> 5;
+    if (st) { asm volatile("" :: "v"(cj[0]), "v"(rb[0]), "v"(eb[0])); ORR_EPI_STAMP(4); }
     int parked = 0;
+    // the query constants of (block i, element e) for this lane: {0.7/sqrt(normA) [* s1], floor - margin, 0.2/terms, int8: query part of the bound}
+    auto qf_of = [&](int i, int e) -> float4 {
+        const int qi = qbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if constexpr (STAGED) return qf_lds[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];     // (the caller clamped past B when staging)
+        else return epi.qf[qi < B ? qi : B - 1];
+    };
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int qg = (qbase + i * 32) >> 5;
-        const int qgc = qg < n_qg ? qg : n_qg - 1;                         // clamped, never branched around
+        // Count words (four bits per query, word k = queries 8 k .. 8 k + 7 of the block) shifted so that element e's query
+        // sits at the COMPILE-TIME nibble e & 3 of word e >> 2: the count is one v_bfe with immediates.
         uint32_t w[NJ][kCountPlanes];
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int p = 0; p < kCountPlanes; ++p)
-                w[j][p] = epi.count_planes ? epi.count_planes[((int64_t)p * n_qg + qgc) * epi.plane_stride + (ok[j] ? cols[j] : n_rows - 1)] : 0u;
+            for (int p = 0; p < kCountPlanes; ++p) w[j][p] = L.w[i][j][p] >> (16 * fh);
+        const int q_left = B - (qbase + i * 32 + 4 * fh);                   // elements with (e & 3) + 8 (e >> 2) >= q_left have no query
+        if constexpr (STAGED) {
+            // Pass 1a, branch-free: could any of the block's 16 x NJ elements of any lane reach its query's floor?  Nothing but
+            // the bound and one compare per element: a row past the end has cj = -inf (its bound is below every floor) and a
+            // query past the batch was staged with a floor of +inf.
+            unsigned long long wave_any = 0ull;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cb = (e & 3) + 8 * (e >> 2);
+                const float4 qf = qf_of(i, e);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
+                    const float a = (float)acc[i][j][e];
+                    const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
+                    wave_any |= __builtin_amdgcn_ballot_w64(!(upper < qf.y));      // NaN bounds (float accumulators that overflowed) are kept
+                }
+            }
+            if (wave_any == 0ull) {
+                if (i == 0) { ORR_EPI_STAMP(5); }
+                continue;
+            }
+        }
+        // Pass 1b: the same tests element by element, parking what passes.  With staged inputs it only runs for a block in
+        // which 1a found something (about one block in fifteen on the bench corpus).
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int bit = (e & 3) + 8 * (e >> 2) + 4 * fh;
-            const int qi = qbase + i * 32 + bit;
-            const float4 qf = epi.qf[qi < B ? qi : B - 1];                 // {0.7/sqrt(normA), floor - margin, 0.2/terms, -}
+            const int cb = (e & 3) + 8 * (e >> 2);
+            const int qi = qbase + i * 32 + cb + 4 * fh;
+            const float4 qf = qf_of(i, e);
+            const bool has_query = cb < q_left;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int p = 0; p < kCountPlanes; ++p) m |= ((w[j][p] >> bit) & 1u) << p;
-                const float a = acc[i][j][e];
-                const float upper = a * (qf.x * rb[j]) + rr[j] + (float)m * qf.z + (ea[j] + qf.w * eb[j]);   // the last term is 0 outside the int8 GEMM
-                // NaN and overflowed sums are never dropped here
-                const bool drop = (upper < qf.y && __builtin_fabsf(a) <= 3.4028234663852886e38f) || qi >= B || !ok[j];
+                const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
+                const float a = (float)acc[i][j][e];                       // int8 GEMM: |I| <= 3072 * 127^2, the conversion costs at most 2^-24
+                // score bound: a (qf.x rb) + recency + keyword credit + (int8) the pair's quantisation bound
+                const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
+                // NaN and overflowed sums (float accumulators only) are never dropped here
+                bool drop = upper < qf.y;
+                if constexpr (!INT_ACC) drop = drop && __builtin_fabsf(a) <= 3.4028234663852886e38f;
+                drop = drop || !has_query || !ok[j];
                 if (!drop) {
                     if (parked < kEpiQueue) {
                         EpiParked pk;
@@ -97,7 +193,10 @@ __device__ __forceinline__ void fused_epilogue(const f32x16 (&acc)[NI][NJ], int 
                 }
             }
         }
+        if (i == 0) { ORR_EPI_STAMP(5); }
     }
+    ORR_EPI_STAMP(6);
+#undef ORR_EPI_STAMP
     if (parked > kEpiQueue) parked = kEpiQueue;
     for (int s = 0; s < parked; ++s) {
         EpiParked pk = queue[s * queue_stride];

@@ -344,10 +344,11 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
     }
 }
 
-// Count planes: planes[p][g][r] bit q = bit p of the keyword match count of query 32 g + q in row r
+// Count words: out[k][g][r], nibble n = the keyword match count of query 32 g + 8 k + n in row r
 // (RecallSearchService.cs:111), so a lane of the scoring epilogue gets the counts of its 32
-// queries for one row from kCountPlanes words.  Queries with more than 15 terms store 15 where any
-// term occurs (the pre-filter then grants them the full keyword credit, an upper bound).
+// queries for one row from kCountPlanes words, one v_bfe each.  Queries with more than 15 terms store 15
+// where any term occurs (the pre-filter then grants them the full keyword credit, an upper bound).
+// The counts are formed bit-sliced (plane p = bit p of the count) and re-packed into nibbles at the end.
 // One wave handles 256 rows x 32 queries at a time: lane (q, h) adds the row bitmaps of query q's
 // terms for the four bitmap words 8 pr + 4 h .. + 3 (one 16-byte load per term) bit-sliced -- 32 rows
 // per word, ripple carry through the planes -- then each plane of each word, a 32 x 32 bit matrix with
@@ -411,8 +412,22 @@ __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int3
             }
             const int64_t row = (Q * 4 + k) * 32 + q;                      // after the transpose this lane holds row q of the word
             if (row < n_rows) {
+                // planes -> NIBBLES: word kk holds the counts of queries 8 kk .. 8 kk + 7 of the group, four bits each (bit p of a
+                // nibble = plane p), so that the epilogue gets a pair's count with one v_bfe_u32 (orr_epilogue.h) instead of
+                // gathering four plane bits
 #pragma unroll
-                for (int p = 0; p < kCountPlanes; ++p) planes[((int64_t)p * n_qg + g) * plane_stride + row] = c[k][p];
+                for (int kk = 0; kk < 4; ++kk) {
+                    uint32_t wv = 0u;
+#pragma unroll
+                    for (int p = 0; p < kCountPlanes; ++p) {
+                        uint32_t x = (c[k][p] >> (8 * kk)) & 0xFFu;          // 8 queries' bits of plane p
+                        x = (x | (x << 12)) & 0x000F000Fu;
+                        x = (x | (x << 6)) & 0x03030303u;
+                        x = (x | (x << 3)) & 0x11111111u;                  // bit n -> bit 4 n
+                        wv |= x << p;
+                    }
+                    planes[((int64_t)kk * n_qg + g) * plane_stride + row] = wv;
+                }
             }
         }
     }
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryCons
         const double margin = 1e-5 * (1.0 + fabs(floor_score));
         o.y = __double2float_rd(floor_score - margin);
     }
-    // count planes saturate at 15: beyond that a row with any match gets the full credit (15 * 0.2/15)
+    // the counts saturate at 15: beyond that a row with any match gets the full credit (15 * 0.2/15)
     o.z = c.n_terms > 0 ? __double2float_ru(0.2 / (double)(c.n_terms > 15 ? 15 : c.n_terms)) : 0.f;
     o.w = 0.f;
     if (i8_qs1) {                                           // int8 screening GEMM: the accumulator is an integer dot

@@ -15,7 +15,7 @@ constexpr int kMaxExactQ = 8;        // queries one launch of the exact dot kern
 constexpr int kMaxScanTerms = 64;    // query terms one launch of the keyword scan carries
 constexpr int kMaxGemvScreenQ = 8;   // queries one launch of the streaming screen (K2g) carries
 constexpr int kMaxI8ScreenQ = 4;     // ... of its int8 form (K2i): two accumulators per query and row
-constexpr int kCountPlanes = 4;      // bit planes of the per-(query,row) keyword match count (saturates at 15)
+constexpr int kCountPlanes = 4;      // 32-bit words per (32 queries, row) of keyword match counts: four bits per query (saturating at 15)
 
 // One selection entry: `key` orders scores (see score_key in the .hip), `pos` is the
 // row's position in the shard's candidate order.  key 0 = empty slot.
@@ -155,7 +155,7 @@ struct FusedEpilogue {
     KwView kw;
     const unsigned long long *tau;     // [B] floor keys
     const float4 *qf;                  // [B] fp32 pre-filter constants (launch_fused_query_consts)
-    const uint32_t *count_planes;      // [kCountPlanes][ceil(B/32)][plane_stride] bit-sliced match counts, or null
+    const uint32_t *count_planes;      // [kCountPlanes][ceil(B/32)][plane_stride] match counts, word k = queries 8k..8k+7 of the group, 4 bits each; or null
     int64_t plane_stride;
     // int8 screening GEMM (K2j) only, else null: per row {se_r, 0.7 (rel_err + 2^-22), rel_hat, 0}; per query s1.
     // The accumulator then holds the integer dot I: dot^ = s1 se_r I, and qf.x / qf.w carry s1 0.7/sqrt(normA)
@@ -165,6 +165,7 @@ struct FusedEpilogue {
     uint32_t *cnt;                     // [B]
     SelEntry *buf;                     // [B][cap]
     uint32_t cap;
+    unsigned long long *stamps;        // diagnostic (ORR_SCREEN_STAMPS=file): s_memtime at the phases of every output tile, else null
 };
 // K2b: S (or the fused epilogue) from three bf16 MFMA products of hi/lo splits (see orr_gemm.hip
 // for the error bound); D % 64 == 0.  q_split_ws: 4*B*D bytes filled by launch_split_queries.

@@ -34,6 +34,8 @@
 #include "orr_epilogue.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <type_traits>
 #include <cstdlib>
 
@@ -100,7 +102,10 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     const uint32_t lane_off = (uint32_t)(wave * 1024 + lane * 16);
     int ring0 = 0;                                                          // stage of this output tile's K-tile 0
     bool first = true;
+    int tile_seq = 0;
+#define ORR_STAMP(k) if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + (k)] = __builtin_amdgcn_s_memtime()
     for (int id = valid_from(blockIdx.x); id < total_ids;) {
+    ORR_STAMP(0);
     const int next_id = valid_from(id + gridDim.x);
     const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
     const int64_t n0 = row_first + (int64_t)nt * kScBN;
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #undef ORR_MM
 #undef ORR_SB
     if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the spare pieces of the last tiles
+    ORR_STAMP(1);
 
     if (!FUSED) {
         if (active)
@@ -230,12 +236,6 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
                 }
             }
     } else {
-        // every wave is done with the stage the queue takes over (its fragment reads were consumed by its MFMAs); a bare
-        // barrier: __syncthreads() would also wait for the next output tile's first K-tiles, which are meant to arrive
-        // during the epilogue
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the parking queue of the epilogue: the stage of this tile's last K-tile, the only one no request is bound for
-        EpiParked *queue = reinterpret_cast<EpiParked *>(lds + ((ring0 + T - 1) % kScNS) * kScStage) + tid;
         // The epilogue's inputs are laundered once per output tile: otherwise everything it derives from them is
         // hoisted out of the persistent loop and stays live across the K loop, whose registers are all spoken for
         // (the compiler then spilt two values INSIDE it, with an s_waitcnt vmcnt(0) per K-tile to get them back).
@@ -245,24 +245,42 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
         uint32_t salt = 0;
         asm volatile("" : "+s"(salt));
+        // ONE trip to global memory per tile, requested here and awaited behind the barrier: this thread's 8 bytes of the
+        // tile's query constants (256 x float4 = 4 KiB, staged in LDS for every wave) and, for the multiplying waves, the
+        // constants and count-plane words of their rows (orr_epilogue.h).  The wait for them is also the wait for the next
+        // tile's first K-tiles, which were requested before.
+        float2 qf_part;
+        {
+            const int q = b0 + (tid >> 1);
+            qf_part = reinterpret_cast<const float2 *>(ep.qf + (q < B ? q : B - 1))[tid & 1];
+            if (q >= B) qf_part = (tid & 1) ? make_float2(0.f, 0.f) : make_float2(0.f, __builtin_huge_valf());   // no query: {0, floor +inf, 0, 0}
+        }
+        EpiTileLoads<LI, 2> pre;
+        if (active) epilogue_issue_loads(pre, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane);
+        // every wave is done with the stage the queue takes over (its fragment reads were consumed by its MFMAs); a bare
+        // barrier: __syncthreads() would also wait for the next output tile's first K-tiles, which are meant to arrive
+        // during the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the parking queue of the epilogue and the query constants: the stage of this tile's last K-tile, the only one no request is bound for
+        unsigned char *stage = lds + ((ring0 + T - 1) % kScNS) * kScStage;
+        EpiParked *queue = reinterpret_cast<EpiParked *>(stage) + tid;
+        float4 *qf_lds = reinterpret_cast<float4 *>(stage + kEpiQueueBytes);
+        reinterpret_cast<float2 *>(qf_lds)[tid] = qf_part;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (active) {
-            if constexpr (I8) {
-                f32x16 accf[LI][2];                                         // |I| <= 3072 * 127^2: the conversion costs at most 2^-24
-#pragma unroll
-                for (int i = 0; i < LI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) accf[i][j][e] = (float)acc[i][j][e];
-                fused_epilogue<LI, 2, true>(accf, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane, queue, 512, salt);
-            } else {
-                fused_epilogue<LI, 2, true>(acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane, queue, 512, salt);
-            }
+            unsigned long long *st = (FUSED && epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
+            // (integer dots go in as they are: |I| <= 3072 * 127^2, the conversion inside costs at most 2^-24)
+            fused_epilogue<LI, 2, true, typename std::conditional<I8, i32x16v, f32x16>::type, true>(
+                acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane, queue, 512, salt, st, &pre, qf_lds + wr * 128);
         }
     }
+    ORR_STAMP(2);
+    if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    ++tile_seq;
     ring0 = (ring0 + T) % kScNS;
     id = next_id;
     }
+#undef ORR_STAMP
 }
 
 // K2g: the same screening pass for 1..8 queries -- no matrix core, a pure stream over the tiled shadow.
@@ -701,18 +719,35 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
     static const int live_max = [] { const char *e = getenv("ORR_SCREEN_LIVE"); return e ? atoi(e) : 0; }();   // 8: always the full tile
+    // ORR_SCREEN_STAMPS=file (diagnostic): every launch appends its workgroups' per-tile phase stamps to the file
+    static const char *stamp_path = getenv("ORR_SCREEN_STAMPS");
+    static unsigned long long *d_stamps = nullptr;
+    constexpr size_t kStampWords = 256 * 64 * 8;
+    FusedEpilogue epi_st = epi;
+    if (stamp_path) {
+        if (!d_stamps && hipMalloc(reinterpret_cast<void **>(&d_stamps), kStampWords * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_stamps, 0, kStampWords * 8, s);
+        epi_st.stamps = d_stamps;
+    }
+    const FusedEpilogue &epi_use = epi_st;
 #define ORR_LAUNCH_I8(L) do { \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, true, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
-                           static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi); } while (0)
+                           static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
     if (live_max == 8 || B > 128) ORR_LAUNCH_I8(8);
     else if (B > 64) ORR_LAUNCH_I8(4);
     else if (B > 32) ORR_LAUNCH_I8(2);
     else ORR_LAUNCH_I8(1);
 #undef ORR_LAUNCH_I8
+    if (stamp_path) {
+        std::vector<unsigned long long> h(kStampWords);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), d_stamps, kStampWords * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(stamp_path, "ab")) { fwrite(h.data(), 8, kStampWords, f); fclose(f); }
+        }
+    }
     return hipGetLastError();
 }
 

@@ -20,11 +20,15 @@ def _is_torch(x) -> bool:
 
 
 def _ptr(x) -> Optional[int]:
-    """Raw address of a numpy array or torch tensor (host or device)."""
+    """Raw address of a numpy array or torch tensor (host or device).  The library reads device memory on its own
+    streams (include/omnirecall_hip.h, conventions): whatever torch still has queued for a CUDA tensor is waited for."""
     if x is None:
         return None
     if _is_torch(x):
         assert x.is_contiguous()
+        if x.is_cuda:
+            import torch
+            torch.cuda.current_stream(x.device).synchronize()
         return x.data_ptr()
     assert x.flags["C_CONTIGUOUS"]
     return x.ctypes.data
@@ -205,6 +209,17 @@ class RecallIndex:
 
     def set_profiling(self, on: bool) -> None:
         N.check(N.hip.orr_index_set_profiling(self._h, 1 if on else 0))
+
+    def search_stats(self, reset: bool = False) -> dict:
+        """orr_index_search_stats: repeats of the cheap passes and what the screening pass kept, since the last reset."""
+        st = N.OrrSearchStats()
+        N.check(N.hip.orr_index_search_stats(self._h, C.byref(st), 1 if reset else 0))
+        d = {n: int(getattr(st, n)) for n, _ in N.OrrSearchStats._fields_ if n != "reserved"}
+        d["survivors_per_query"] = d["survivors_total"] / d["survivor_samples"] if d["survivor_samples"] else None
+        return d
+
+    def reset_search_stats(self) -> None:
+        N.check(N.hip.orr_index_search_stats(self._h, None, 1))
 
     def kernel_stats(self) -> dict:
         arr = (N.OrrKernelStat * 32)()

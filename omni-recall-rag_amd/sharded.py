@@ -1,103 +1,71 @@
 """Row-sharded search across the GPUs of one node: one process per GPU, the corpus
 split into contiguous ranges of the global candidate order.
 
-Per step:  all-gather the queries (every rank may originate some)  ->  every rank
-scores ALL queries against its own shard (orr_search_shard, HBM-bound: the shard is
-read once for the whole batch)  ->  ONE all-gather of the per-shard candidate
-records over RCCL/xGMI  ->  every rank finishes the queries on the host
-(orr_merge_candidates) and keeps the ones it originated.  No all-reduce anywhere.
+Per step:  the queries reach every rank (all-gather of what each rank originates, or a
+broadcast from the one rank that originates the batch)  ->  every rank scores ALL queries
+against its own shard (orr_search_shard: the shard is read once for the whole batch)  ->
+ONE all-gather of the per-shard candidate records over RCCL/xGMI  ->  every rank finishes
+the queries on the host (orr_merge_candidates) from identical bytes, so the
+escalate-or-not decision needs no further collective.  No all-reduce anywhere.
+
+Query exchange format (length-prefixed, no per-query size limit): one block per rank,
+    [4 x int64: queries, dim, term-section bytes, reserved]
+    [queries x dim fp32]                                   the vectors
+    [u32 query_term_off[queries+1]] [u32 term_off[T+1]] [term bytes]   the ABI's packed terms
+The first collective carries the header, the vectors and the first TERM_BUDGET bytes per query
+of the term section; only when some rank's term section is longer does a second collective
+carry the remainders (every rank sees every header, so all take the same branch).
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .index import CAND_DTYPE, PackedTerms, RecallIndex, merge_candidates, pack_terms
+from .index import CAND_DTYPE, PackedTerms, merge_candidates, pack_terms
 
-TERM_SLOT = 256        # bytes reserved per query for its packed terms
-
-
-def _slots_from_packed(pool: np.ndarray, toff: np.ndarray, qoff: np.ndarray) -> np.ndarray:
-    """ABI term arrays -> one TERM_SLOT-byte slot per query: [n][len_0 .. len_{n-1}][bytes...], zero padded.
-    Vectorised: a batch of 1024 queries costs a fraction of a millisecond; a handful of queries (the
-    one-query-per-rank step of the bench) is quicker in plain Python than through a dozen numpy calls."""
-    B = int(qoff.shape[0]) - 1
-    slots = np.zeros((B, TERM_SLOT), dtype=np.uint8)
-    if B == 0:
-        return slots
-    if B <= 4:
-        to, qo = toff.tolist(), qoff.tolist()
-        raw = pool.tobytes()
-        for b in range(B):
-            t0, t1 = qo[b], qo[b + 1]
-            lens = [to[t + 1] - to[t] for t in range(t0, t1)]
-            if t1 - t0 > 255 or (lens and max(lens) > 255):
-                raise ValueError("term longer than 255 bytes" if lens and max(lens) > 255 else
-                                 "query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
-            body = bytes([t1 - t0]) + bytes(lens) + raw[to[t0]:to[t1]]
-            if len(body) > TERM_SLOT:
-                raise ValueError("query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
-            slots[b, :len(body)] = np.frombuffer(body, dtype=np.uint8)
-        return slots
-    toff = toff.astype(np.int64)
-    qoff = qoff.astype(np.int64)
-    lens = np.diff(toff)                                    # per term
-    n = np.diff(qoff)                                       # terms per query
-    qbytes = toff[qoff[1:]] - toff[qoff[:-1]]               # term bytes per query
-    if lens.size and int(lens.max()) > 255:
-        raise ValueError("term longer than 255 bytes")
-    if int(n.max()) > 255 or int((1 + n + qbytes).max()) > TERM_SLOT:
-        raise ValueError("query terms do not fit the %d-byte exchange slot" % TERM_SLOT)
-    slots[:, 0] = n
-    tq = np.repeat(np.arange(B), n)                         # query of each term
-    slots[tq, 1 + np.arange(lens.size) - qoff[tq]] = lens
-    total = int(toff[-1])
-    bq = np.repeat(np.arange(B), qbytes)                    # query of each term byte
-    slots[bq, 1 + n[bq] + np.arange(total) - toff[qoff[bq]]] = pool[:total]
-    return slots
+TERM_BUDGET = 256      # bytes of packed terms per query that ride in the first collective
+HEADER_BYTES = 32
 
 
-def _packed_from_slots(slots: np.ndarray) -> PackedTerms:
-    """The inverse, for all gathered queries at once."""
-    B = int(slots.shape[0])
-    if B <= 16:                                             # a few queries: plain Python beats the masked gathers below
-        pool, toff, qoff = bytearray(), [0], [0]
-        for row in slots:
-            raw = row.tobytes()
-            n = raw[0]
-            at = 1 + n
-            for ln in raw[1:1 + n]:
-                pool += raw[at:at + ln]
-                at += ln
-                toff.append(len(pool))
-            qoff.append(len(toff) - 1)
-        pool.append(0)
-        return PackedTerms((np.frombuffer(bytes(pool), dtype=np.uint8), np.asarray(toff, dtype=np.uint32),
-                            np.asarray(qoff, dtype=np.uint32)))
-    n = slots[:, 0].astype(np.int64)
-    col = np.arange(TERM_SLOT, dtype=np.int64)[None, :]
-    len_mask = (col >= 1) & (col < 1 + n[:, None])
-    lens = slots[len_mask].astype(np.int64)                 # row-major: query order, then term order
-    qoff = np.zeros(B + 1, dtype=np.int64)
-    np.cumsum(n, out=qoff[1:])
-    toff = np.zeros(lens.size + 1, dtype=np.int64)
-    np.cumsum(lens, out=toff[1:])
-    qbytes = toff[qoff[1:]] - toff[qoff[:-1]]
-    byte_mask = (col >= 1 + n[:, None]) & (col < 1 + n[:, None] + qbytes[:, None])
-    pool = np.concatenate([slots[byte_mask], np.zeros(1, dtype=np.uint8)])
-    return PackedTerms((np.ascontiguousarray(pool), toff.astype(np.uint32), qoff.astype(np.uint32)))
+def _term_section(packed) -> np.ndarray:
+    """ABI term arrays -> one byte string [qoff u32 x (B+1)][toff u32 x (T+1)][pool]."""
+    pool, toff, qoff = packed
+    qoff = np.ascontiguousarray(qoff, dtype=np.uint32)
+    t_lo, t_hi = int(qoff[0]), int(qoff[-1])
+    toff = np.ascontiguousarray(toff[t_lo:t_hi + 1], dtype=np.uint32)
+    p_lo, p_hi = (int(toff[0]), int(toff[-1])) if toff.size else (0, 0)
+    parts = [(qoff - np.uint32(t_lo)).view(np.uint8), (toff - np.uint32(p_lo)).view(np.uint8),
+             np.ascontiguousarray(pool[p_lo:p_hi], dtype=np.uint8)]
+    return np.concatenate(parts)
 
 
-def _pack_terms_fixed(terms: Sequence[bytes]) -> np.ndarray:
-    """One query's slot (kept for tests and small callers)."""
-    return _slots_from_packed(*pack_terms([terms]))[0]
+def _parse_term_section(sec: np.ndarray, n_queries: int):
+    """The inverse: (pool, toff, qoff) of one rank."""
+    qoff = sec[:4 * (n_queries + 1)].view(np.uint32)
+    n_terms = int(qoff[-1])
+    at = 4 * (n_queries + 1)
+    toff = sec[at:at + 4 * (n_terms + 1)].view(np.uint32)
+    at += 4 * (n_terms + 1)
+    pool = sec[at:at + int(toff[-1])]
+    return pool, toff, qoff
 
 
-def _unpack_terms_fixed(slot: np.ndarray) -> List[bytes]:
-    return _packed_from_slots(slot[None, :])[0]
+def _concat_packed(parts) -> PackedTerms:
+    """Packed term arrays of several ranks -> those of the concatenated batch."""
+    pools, toffs, qoffs = [], [np.zeros(1, dtype=np.int64)], [np.zeros(1, dtype=np.int64)]
+    p_base = t_base = 0
+    for pool, toff, qoff in parts:
+        pools.append(pool)
+        toffs.append(toff[1:].astype(np.int64) + p_base)
+        qoffs.append(qoff[1:].astype(np.int64) + t_base)
+        p_base += int(toff[-1])
+        t_base += int(qoff[-1])
+    pools.append(np.zeros(1, dtype=np.uint8))              # the ABI never reads it; keeps the pointer valid for empty pools
+    return PackedTerms((np.ascontiguousarray(np.concatenate(pools)), np.concatenate(toffs).astype(np.uint32),
+                        np.concatenate(qoffs).astype(np.uint32)))
 
 
 class ShardedRecallSearch:
@@ -111,10 +79,21 @@ class ShardedRecallSearch:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit) -> records [B,kprime+1]
-        self._shard_search = shard_search or (lambda q, t, now, kp, lim, out=None:
-                                              self.index.search_shard(q, t, now, kp, lim, out=out))
+        # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit, out=, mode=) -> records [B,kprime+1]
+        self._shard_search = shard_search or self._index_shard_search
         self._pinned = {}                      # name -> pinned host staging tensor (device runs only)
+        self.collectives = 0                   # data-path collectives issued so far (diagnostic)
+        self.escalations = 0                   # batches repeated with the exact pass or a larger k'
+
+    def _index_shard_search(self, q, terms, now, kprime, limit, out=None, mode=0):
+        # mode 0: the library picks the pass; 2: the exact pass (escalation after a failed certificate)
+        if mode:
+            self.index.set_option("shard_pass", mode)
+        try:
+            return self.index.search_shard(q, terms, now, kprime, limit, out=out)
+        finally:
+            if mode:
+                self.index.set_option("shard_pass", 0)
 
     def _to_host(self, name: str, t: torch.Tensor) -> np.ndarray:
         """Device tensor -> numpy through a reused pinned buffer (one asynchronous copy + one stream sync instead of
@@ -130,6 +109,135 @@ class ShardedRecallSearch:
         torch.cuda.current_stream(t.device).synchronize()
         return view.numpy()
 
+    def rccl_ranks_seen(self) -> int:
+        """Ranks that answer one all-gather on this group's backend (bench evidence that the RCCL path ran)."""
+        if self.world == 1:
+            return 1
+        mine = torch.tensor([self.rank], dtype=torch.int64, device=self.device)
+        allr = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(allr, mine, group=self.group)
+        return int(torch.unique(allr.cpu()).numel())
+
+    # ---- exchange 1: the queries
+    def _block(self, q_local, packed, B_local: int, dim: int, first_bytes: int):
+        sec = _term_section(packed)
+        vec_bytes = 4 * dim * B_local
+        head = np.array([B_local, dim, sec.size, 0], dtype=np.int64).view(np.uint8)
+        total = HEADER_BYTES + vec_bytes + sec.size
+        block = torch.zeros(max(first_bytes, total), dtype=torch.uint8, device=self.device)
+        block[:HEADER_BYTES] = torch.from_numpy(head.copy()).to(self.device, non_blocking=True)
+        if vec_bytes:
+            block[HEADER_BYTES:HEADER_BYTES + vec_bytes] = q_local.contiguous().view(torch.uint8).reshape(-1)
+        if sec.size:
+            block[HEADER_BYTES + vec_bytes:total] = torch.from_numpy(sec).to(self.device, non_blocking=True)
+        return block, total
+
+    def _gather_queries(self, q_local, terms_local, B_local: int, dim: int):
+        """Every rank originates B_local queries.  Returns (q_all device [B,dim] or None, q_host, terms_all)."""
+        W = self.world
+        first = HEADER_BYTES + 4 * dim * B_local + TERM_BUDGET * B_local
+        first = (first + 15) // 16 * 16
+        block, total = self._block(q_local, pack_terms(terms_local), B_local, dim, first)
+        if W > 1:
+            got = torch.empty(W * first, dtype=torch.uint8, device=self.device)
+            dist.all_gather_into_tensor(got, block[:first].contiguous(), group=self.group)
+            got = got.reshape(W, first)
+            self.collectives += 1
+        else:
+            got = block[:first].reshape(1, first)
+        host = self._to_host("queries", got)
+        heads = host[:, :HEADER_BYTES].copy().view(np.int64).reshape(W, 4)
+        totals = HEADER_BYTES + 4 * heads[:, 1] * heads[:, 0] + heads[:, 2]
+        rest_max = int(max(0, (totals - first).max()))
+        rest_host = None
+        if rest_max > 0:                                     # some rank's terms did not fit: one more collective, same on every rank
+            rest_max = (rest_max + 15) // 16 * 16
+            mine = torch.zeros(rest_max, dtype=torch.uint8, device=self.device)
+            if total > first:
+                mine[:total - first] = block[first:total]
+            if W > 1:
+                rest = torch.empty(W * rest_max, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(rest, mine, group=self.group)
+                rest = rest.reshape(W, rest_max)
+                self.collectives += 1
+            else:
+                rest = mine.reshape(1, rest_max)
+            rest_host = self._to_host("queries_rest", rest)
+        parts, vecs = [], []
+        for r in range(W):
+            b_r, d_r, sec_bytes = int(heads[r, 0]), int(heads[r, 1]), int(heads[r, 2])
+            if b_r != B_local or d_r != dim:
+                raise ValueError("every rank must call search() with the same batch size and dimension")
+            raw = host[r] if rest_host is None else np.concatenate([host[r], rest_host[r]])
+            vb = 4 * dim * b_r
+            if dim:
+                vecs.append(raw[HEADER_BYTES:HEADER_BYTES + vb])
+            parts.append(_parse_term_section(np.ascontiguousarray(raw[HEADER_BYTES + vb:HEADER_BYTES + vb + sec_bytes]), b_r))
+        B = W * B_local
+        q_host = np.ascontiguousarray(np.concatenate(vecs)).view(np.float32).reshape(B, dim) if dim else None
+        if dim and self.device.type == "cuda":
+            q_all = got[:, HEADER_BYTES:HEADER_BYTES + 4 * dim * B_local].contiguous().view(torch.float32).reshape(B, dim)
+        else:
+            q_all = torch.from_numpy(q_host) if dim else None
+        return q_all, q_host, _concat_packed(parts)
+
+    def _broadcast_queries(self, q, terms, origin: int):
+        """Rank `origin` holds the whole batch (the others pass None): header, then one block."""
+        W = self.world
+        head = torch.zeros(4, dtype=torch.int64, device=self.device)
+        block = None
+        if self.rank == origin:
+            B = len(terms)
+            dim = int(q.shape[1]) if q is not None and q.numel() else 0
+            block, total = self._block(q, pack_terms(terms), B, dim, 0)
+            head = torch.tensor([B, dim, total, 0], dtype=torch.int64, device=self.device)
+        if W > 1:
+            dist.broadcast(head, src=origin, group=self.group)
+            self.collectives += 1
+        B, dim, total = (int(x) for x in head.cpu()[:3])
+        if self.rank != origin:
+            block = torch.empty(total, dtype=torch.uint8, device=self.device)
+        if W > 1:
+            dist.broadcast(block[:total], src=origin, group=self.group)
+            self.collectives += 1
+        host = self._to_host("queries", block[:total])
+        vb = 4 * dim * B
+        q_host = np.ascontiguousarray(host[HEADER_BYTES:HEADER_BYTES + vb]).view(np.float32).reshape(B, dim).copy() if dim else None
+        sec_bytes = int(host[:HEADER_BYTES].copy().view(np.int64)[2])
+        terms_all = _concat_packed([_parse_term_section(np.ascontiguousarray(host[HEADER_BYTES + vb:HEADER_BYTES + vb + sec_bytes]).copy(), B)])
+        if dim and self.device.type == "cuda":
+            q_all = block[HEADER_BYTES:HEADER_BYTES + vb].view(torch.float32).reshape(B, dim)
+        else:
+            q_all = torch.from_numpy(q_host) if dim else None
+        return q_all, q_host, terms_all, B
+
+    # ---- local scoring, exchange 2, host finish
+    def _score_and_merge(self, q_all, q_host, terms_all, B: int, now_ticks: int, topk: int, candidate_limit: int, kprime: int):
+        W = self.world
+        mode = 0
+        while True:
+            rec_bytes = B * (kprime + 1) * CAND_DTYPE.itemsize
+            mine = torch.empty(rec_bytes, dtype=torch.uint8, device=self.device)
+            self._shard_search(q_all, terms_all, now_ticks, kprime, candidate_limit, out=mine, mode=mode)
+            if W > 1:
+                allrec = torch.empty(W * rec_bytes, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(allrec, mine, group=self.group)
+                self.collectives += 1
+            else:
+                allrec = mine
+            recs = self._to_host("records", allrec).view(CAND_DTYPE).reshape(W, B, kprime + 1)
+            # Every rank finishes EVERY query from the same gathered bytes, so all ranks reach the
+            # same "escalate or not" decision without another collective.
+            rows, scores, counts, unc = merge_candidates(recs, self.index_dim, q_host, terms_all, now_ticks, topk)
+            total = int(recs[:, 0, kprime]["order_key"].sum())
+            if unc == 0 or kprime >= total:
+                return rows, scores, counts
+            self.escalations += 1
+            if mode == 0:
+                mode = 2                                     # first the exact pass at the same k' (ties at the cut, overflowing survivor buffers)
+            else:
+                kprime = min(max(total, 1), kprime * 4)      # then a wider k' (masses of exact ties)
+
     def search(self, q_local: torch.Tensor, terms_local: Sequence[Sequence[bytes]], now_ticks: int, topk: int,
                candidate_limit: int, kprime: int = 32):
         """q_local: [B_local, dim] float32 on self.device (dim may be 0).  Every rank must call with
@@ -137,44 +245,15 @@ class ShardedRecallSearch:
         (rows [B_local,k], scores [B_local,k], counts [B_local])."""
         B_local = len(terms_local)
         dim = int(q_local.shape[1]) if q_local is not None and q_local.numel() else 0
-        W = self.world
-        # ---- exchange 1: queries (vector bytes + packed terms in one buffer per query)
-        vec_bytes = 4 * dim
-        slot = vec_bytes + TERM_SLOT
-        send = torch.empty((B_local, slot), dtype=torch.uint8, device=self.device)
-        if dim:
-            send[:, :vec_bytes] = q_local.contiguous().view(torch.uint8).reshape(B_local, vec_bytes)
-        tslots = _slots_from_packed(*pack_terms(terms_local))
-        send[:, vec_bytes:] = torch.from_numpy(tslots).to(self.device, non_blocking=True)
-        if W > 1:
-            allq = torch.empty((W * B_local, slot), dtype=torch.uint8, device=self.device)
-            dist.all_gather_into_tensor(allq, send, group=self.group)
-        else:
-            allq = send
-        B = W * B_local
-        q_all = allq[:, :vec_bytes].contiguous().view(torch.float32).reshape(B, dim) if dim else None
-        allq_host = self._to_host("queries", allq)   # ONE download: vectors (for the exact normA) + terms
-        q_host = np.ascontiguousarray(allq_host[:, :vec_bytes]).view(np.float32).reshape(B, dim) if dim else None
-        terms_all = _packed_from_slots(allq_host[:, vec_bytes:])   # ABI form, packed once for both calls below
+        q_all, q_host, terms_all = self._gather_queries(q_local, terms_local, B_local, dim)
+        rows, scores, counts = self._score_and_merge(q_all, q_host, terms_all, self.world * B_local, now_ticks, topk,
+                                                     candidate_limit, kprime)
+        lo = self.rank * B_local
+        return rows[lo:lo + B_local], scores[lo:lo + B_local], counts[lo:lo + B_local]
 
-        while True:
-            # ---- local scoring of every query against this shard
-            rec_bytes = B * (kprime + 1) * CAND_DTYPE.itemsize
-            mine = torch.empty(rec_bytes, dtype=torch.uint8, device=self.device)
-            self._shard_search(q_all, terms_all, now_ticks, kprime, candidate_limit, out=mine)
-            # ---- exchange 2: ONE all-gather of the per-shard top-k' records
-            if W > 1:
-                allrec = torch.empty(W * rec_bytes, dtype=torch.uint8, device=self.device)
-                dist.all_gather_into_tensor(allrec, mine, group=self.group)
-            else:
-                allrec = mine
-            recs = self._to_host("records", allrec).view(CAND_DTYPE).reshape(W, B, kprime + 1)
-            # Every rank finishes EVERY query from the same gathered bytes, so all ranks reach the
-            # same "escalate or not" decision without another collective.
-            rows, scores, counts, unc = merge_candidates(recs, self.index_dim, q_host, terms_all, now_ticks, topk)
-            lo = self.rank * B_local
-            rows, scores, counts = rows[lo:lo + B_local], scores[lo:lo + B_local], counts[lo:lo + B_local]
-            total = int(recs[:, 0, kprime]["order_key"].sum())
-            if unc == 0 or kprime >= total:
-                return rows, scores, counts
-            kprime = min(max(total, 1), kprime * 4)
+    def search_from(self, origin: int, q, terms, now_ticks: int, topk: int, candidate_limit: int, kprime: int = 32):
+        """One rank originates the whole batch (q [B, dim] on its device, terms; the others pass None, None):
+        broadcast, score on every shard, one all-gather of records, finish.  Every rank returns the results of
+        all B queries (rows [B,k], scores [B,k], counts [B])."""
+        q_all, q_host, terms_all, B = self._broadcast_queries(q, terms, origin)
+        return self._score_and_merge(q_all, q_host, terms_all, B, now_ticks, topk, candidate_limit, kprime)

@@ -100,23 +100,25 @@ def planted_rows(b0: int, B: int, n_total: int, seed: int = SEED) -> List[int]:
 
 def query_vectors(b0: int, B: int, dim: int, n_total: int, device="cpu", seed: int = SEED) -> torch.Tensor:
     """q_b = e[r*_b] + 0.25 * noise_b: the planted row r*_b is the cosine winner."""
-    out = torch.empty((B, dim), dtype=torch.float32, device=device)
-    for i, r in enumerate(planted_rows(b0, B, n_total, seed)):
-        e = embeddings(r, 1, dim, device, seed)[0]
-        c = torch.arange(dim, dtype=torch.int64, device=device)
-        noise = _unit_fixed(splitmix64(((b0 + i) * dim + c) ^ (seed + 1)))
-        out[i] = e + 0.25 * noise
-    return out
+    r = torch.tensor(planted_rows(b0, B, n_total, seed), dtype=torch.int64, device=device).unsqueeze(1)
+    c = torch.arange(dim, dtype=torch.int64, device=device).unsqueeze(0)
+    b = torch.arange(b0, b0 + B, dtype=torch.int64, device=device).unsqueeze(1)
+    e = _unit_fixed(splitmix64((r * dim + c) ^ seed))                      # = embeddings(r, 1, dim) row by row
+    noise = _unit_fixed(splitmix64((b * dim + c) ^ (seed + 1)))
+    return (e + 0.25 * noise).contiguous()
 
 
 def query_texts(b0: int, B: int, n_total: int, seed: int = SEED) -> List[str]:
     """Three tokens of the planted row plus stop-word filler in mixed case."""
+    rows = torch.tensor(planted_rows(b0, B, n_total, seed), dtype=torch.int64).unsqueeze(1)
+    b = torch.arange(b0, b0 + B, dtype=torch.int64).unsqueeze(1)
+    j = (7 * b + 11 * torch.arange(3, dtype=torch.int64).unsqueeze(0)) % TOKENS_PER_ROW        # [B, 3] token slots
+    picks = (splitmix64((rows * TOKENS_PER_ROW + j) ^ (seed + 3)) & (VOCAB - 1)).tolist()        # = token_ids(row)[slot]
+    tab = _vocab_table("cpu")[:, :WORD_LEN].numpy()
+    f = STOP_FILLERS
     texts = []
-    for i, r in enumerate(planted_rows(b0, B, n_total, seed)):
-        ids = token_ids(r, 1, "cpu", seed)[0]
-        b = b0 + i
-        picks = [int(ids[(7 * b + 11 * k) % TOKENS_PER_ROW]) for k in range(3)]
-        w = [vocab_word(t).decode() for t in picks]
-        f = STOP_FILLERS
-        texts.append(f"{f[b % 5].capitalize()} {w[0]} {f[(b + 1) % 5]} {w[1].upper()} {w[2]}")
+    for i in range(B):
+        w = [bytes(tab[t]).decode() for t in picks[i]]
+        bb = b0 + i
+        texts.append(f"{f[bb % 5].capitalize()} {w[0]} {f[(bb + 1) % 5]} {w[1].upper()} {w[2]}")
     return texts

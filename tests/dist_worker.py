@@ -28,7 +28,7 @@ def oracle_shard_search(P, orc, c, lo, hi):
     """Returns shard_search(q, terms, now, kprime, limit, out=...) over rows [lo, hi)."""
     import torch
 
-    def search(q_all, terms_all, now, kprime, limit, out=None):
+    def search(q_all, terms_all, now, kprime, limit, out=None, mode=0):
         B = len(terms_all)
         n_part = max(0, min(max(1, limit) - lo, hi - lo))
         rec = np.zeros((B, kprime + 1), dtype=P.CAND_DTYPE)
@@ -65,7 +65,7 @@ def oracle_shard_search(P, orc, c, lo, hi):
     return search
 
 
-def run(rank, world, port, n, dim, seed, result_path, use_gpu=False):
+def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_queries=False):
     import torch
     import torch.distributed as dist
     import importlib
@@ -99,12 +99,39 @@ def run(rank, world, port, n, dim, seed, result_path, use_gpu=False):
             orow, osc, _ = corpus.search(q[i].numpy(), texts[i], 639144000000000000, topk, candidate_limit=limit)
             ok = list(rows[i, :counts[i]]) == list(orow) and np.array_equal(scores[i, :counts[i]], osc)
             results.append(bool(ok))
+    expected = 8
+    if long_queries:
+        # rank 1 originates a query whose terms alone exceed the first collective's budget; rank 0 one with 300 terms
+        long_text = " ".join(["kubernetes"] + ["w%04dxyzxyzxyzxyz" % i for i in range(60)]) if rank == 1 else \
+                    " ".join(["helm"] + ["t%d" % i for i in range(300)])
+        texts = [long_text, "alpha"]
+        terms = [P.text.query_terms(t) for t in texts]
+        assert sum(len(t) for t in terms[0]) > 255
+        q = torch.from_numpy(rng.standard_normal((B_local, dim)).astype(np.float32))
+        before = front.collectives
+        rows, scores, counts = front.search(q, terms, 639144000000000000, 5, n, kprime=8)
+        assert front.collectives - before >= 3, "the long terms must have taken the second query collective"
+        corpus = orc.OracleCorpus(c["emb"], c["created"], c["contents"])
+        for i in range(B_local):
+            orow, osc, _ = corpus.search(q[i].numpy(), texts[i], 639144000000000000, 5, candidate_limit=n)
+            results.append(bool(list(rows[i, :counts[i]]) == list(orow) and np.array_equal(scores[i, :counts[i]], osc)))
+        # the one-origin form: rank 0 holds the whole batch, the others pass nothing
+        qb = torch.from_numpy(np.random.default_rng(5).standard_normal((3, dim)).astype(np.float32))
+        tb = ["alpha the helm", long_text if rank == 0 else "", "GAMMA zzz"]
+        rows, scores, counts = front.search_from(0, qb if rank == 0 else None,
+                                                 [P.text.query_terms(t) for t in tb] if rank == 0 else None,
+                                                 639144000000000000, 4, n, kprime=6)
+        tb0 = ["alpha the helm", " ".join(["helm"] + ["t%d" % i for i in range(300)]), "GAMMA zzz"]
+        for i in range(3):
+            orow, osc, _ = corpus.search(qb[i].numpy(), tb0[i], 639144000000000000, 4, candidate_limit=n)
+            results.append(bool(list(rows[i, :counts[i]]) == list(orow) and np.array_equal(scores[i, :counts[i]], osc)))
+        expected += B_local + 3
     dist.barrier()
     dist.destroy_process_group()
     with open(result_path + ".%d" % rank, "w") as f:
-        f.write("ok" if all(results) and len(results) == 8 else "FAIL %r" % results)
+        f.write("ok" if all(results) and len(results) == expected else "FAIL %r" % results)
 
 
 if __name__ == "__main__":
     run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7],
-        use_gpu=len(sys.argv) > 8 and sys.argv[8] == "gpu")
+        use_gpu=len(sys.argv) > 8 and sys.argv[8] == "gpu", long_queries=len(sys.argv) > 9 and sys.argv[9] == "long")

@@ -446,13 +446,19 @@ def test_two_stage_batched_pass_matches_oracle():
     texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
     terms = [P.text.query_terms(t) for t in texts]
     corpus = orc.OracleCorpus(emb, created, contents)
-    # a query on the 20,000 identical rows overflows its survivor buffer: the batch is repeated unfused
+    # a query on the 20,000 identical rows overflows its survivor buffer: THAT QUERY ALONE goes through further passes
+    # (larger buffers sized from the measured count first), the other 129 keep the results of the first pass
     q_over = qs.copy()
     q_over[5] = emb[100_000]
     idx.set_profiling(True)
+    idx.reset_search_stats()
     rows, scores, counts = idx.search(q_over, terms, NOW, 10, candidate_limit=n)
     st = idx.kernel_stats()
-    assert st["screen_i8_prefix"]["launches"] == 1 and st["gemm_dot_bf16x3"]["launches"] == 1, st   # int8 prefix pass + the unfused repeat
+    ss = idx.search_stats()
+    assert st["screen_i8_prefix"]["launches"] == 1 and st["screen_i8_fused"]["launches"] == 1 and "gemm_dot_bf16x3" not in st, st
+    assert ss["overflowed_queries"] >= 1 and ss["buffer_growths"] >= 1 and ss["survivors_max"] >= 20_000, ss
+    assert ss["passes"] >= 2 and ss["requeried"] == ss["passes"] - 1, ss        # every repeat carried exactly one query
+    assert ss["survivor_capacity"] >= 20_000, ss
     idx.set_profiling(False)
     for b in (0, 5, 6):
         orow, osc, _ = corpus.search(q_over[b], texts[b], NOW, 10, candidate_limit=n, threads=8)

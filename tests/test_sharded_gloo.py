@@ -52,43 +52,33 @@ def test_row_sharded_search_real_shards_on_one_gpu(tmp_path):
     _run_world(tmp_path, 3, 3000, 128, extra=("gpu",))
 
 
-def test_term_slot_roundtrip():
-    import importlib
-    import __graft_entry__ as graft
-    graft.load_package()
-    sh = importlib.import_module(graft.PKG_NAME + ".sharded")
-    for terms in ([], [b"a"], [b"kubernetes", "naïve".encode(), b"x" * 100]):
-        assert sh._unpack_terms_fixed(sh._pack_terms_fixed(terms)) == terms
-    with pytest.raises(ValueError):
-        sh._pack_terms_fixed([b"y" * 200, b"z" * 100])
-
-
-def test_term_slots_round_trip_for_a_whole_batch():
-    """The exchange slots are built from and parsed back into the ABI's packed arrays with numpy."""
+def test_term_sections_round_trip():
+    """The query exchange carries the ABI's packed term arrays length-prefixed: no per-query or per-term size limit."""
     import importlib
     import numpy as np
     from helpers import pkg
     P = pkg()
     sh = importlib.import_module("omni_recall_rag_amd.sharded")
-    batch = [[b"alpha", b"beta"], [], [b"x" * 254], [b"\xc3\xa9t\xc3\xa9", b"k8s", b"a"], [b"q"] * 100]
-    packed = P.pack_terms(batch)
-    slots = sh._slots_from_packed(*packed)
-    assert slots.shape == (len(batch), sh.TERM_SLOT) and slots.dtype == np.uint8
-    back = sh._packed_from_slots(slots)
-    assert len(back) == len(batch)
-    assert all(np.array_equal(a, b) for a, b in zip(packed, back.arrays))
-    assert [back[b] for b in range(len(batch))] == batch and list(back) == batch
-    assert all(np.array_equal(a, b) for a, b in zip(P.pack_terms(back), packed))      # PackedTerms passes through
-    # a few queries take plain-Python paths, more the vectorised ones: every size round-trips to the same arrays
-    rng = np.random.default_rng(3)
-    for size in (1, 2, 4, 5, 16, 17, 40):
-        many = [[bytes(rng.integers(97, 123, int(rng.integers(1, 12))).astype(np.uint8)) for _ in range(int(rng.integers(0, 6)))]
-                for _ in range(size)]
-        pk = P.pack_terms(many)
-        sl = sh._slots_from_packed(*pk)
-        bk = sh._packed_from_slots(sl)
-        assert list(bk) == many and all(np.array_equal(a, b) for a, b in zip(pk, bk.arrays)), size
-        assert np.array_equal(sl, np.stack([sh._slots_from_packed(*P.pack_terms([q]))[0] for q in many])), size
-    for bad in ([[b"y" * 256]], [[b"y" * 200, b"z" * 100]], [[b"a"], [b"y" * 256], [], [], []], [[b"q"] * 256]):
-        with pytest.raises(ValueError):
-            sh._slots_from_packed(*P.pack_terms(bad))
+    batches = [[[b"alpha", b"beta"], [], [b"x" * 254], [b"\xc3\xa9t\xc3\xa9", b"k8s", b"a"], [b"q"] * 100],
+               [[b"y" * 300, b"z" * 1000]], [[]], [[b"t%d" % i for i in range(400)], [b"w" * 70000]]]
+    parts = []
+    for batch in batches:
+        packed = P.pack_terms(batch)
+        sec = sh._term_section(packed)
+        back = sh._parse_term_section(sec, len(batch))
+        one = sh._concat_packed([back])
+        assert list(one) == batch
+        assert np.array_equal(one.arrays[1], packed[1]) and np.array_equal(one.arrays[2], packed[2])
+        parts.append(back)
+    allq = sh._concat_packed(parts)                       # several ranks' sections -> the whole batch, in rank order
+    assert list(allq) == [q for batch in batches for q in batch]
+    # a section cut out of the middle of a larger packed batch (qoff[0] > 0) is rebased
+    whole = P.pack_terms(batches[0])
+    sub = (whole[0], whole[1], whole[2][2:5])
+    assert list(sh._concat_packed([sh._parse_term_section(sh._term_section(sub), 2)])) == batches[0][2:4]
+
+
+def test_long_queries_over_gloo(tmp_path):
+    """A query with more than 255 bytes of terms (the round-1 exchange refused it) and one with 300 terms go through
+    the second, variable-length collective and still equal the oracle."""
+    _run_world(tmp_path, 2, 120, 8, extra=("cpu", "long"))
