@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG, "libomnirecall_hip.so")
+HIP_LIB_PATH = os.environ.get("ORR_HIP_LIB") or os.path.join(_PKG, "libomnirecall_hip.so")    # (the override: A/B builds of one kernel on one box)
 HOST_LIB_PATH = os.path.join(_PKG, "libomnirecall_host.so")
 
 

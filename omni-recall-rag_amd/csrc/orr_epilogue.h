@@ -38,8 +38,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 // two forms: 1a BRANCH-FREE over a block of 32 queries, keeping only the wave-wide OR of the answers (the v_cmp
 // results OR-ed in scalar registers); 1b, the element-by-element form with the parking code, runs only for the rare
 // block in which 1a found something.
-constexpr int kEpiQueue = 7;            // parked elements per thread (7 x 8 B x 512 threads = 28 KiB: the stage's last 4 KiB hold the query constants)
-constexpr int kEpiQueueBytes = kEpiQueue * 8 * 512;
+constexpr int kEpiQueue = 8;            // parked elements per thread (default; the screening GEMM keeps 3: its LDS belongs to the operand rings)
 struct EpiParked { float a; uint32_t idx; };
 
 // Everything pass 1 reads from global memory for one output tile and one lane, as loaded (no arithmetic on it yet, so
@@ -83,7 +82,7 @@ __device__ __forceinline__ void epilogue_issue_loads(EpiTileLoads<NI, NJ> &L, in
 //
 // pre / qf_lds (STAGED): the caller's pre-issued loads and the tile's query constants in LDS, indexed by
 // [query - qbase]; otherwise (orr_gemm.hip) everything is loaded here and only pass 1b runs.
-template <int NI, int NJ, bool RESCORED, typename ACC = f32x16, bool STAGED = false>
+template <int NI, int NJ, bool RESCORED, typename ACC = f32x16, bool STAGED = false, int QDEPTH = kEpiQueue>
 __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qbase, int64_t colbase, int32_t B,
                                                int64_t n_rows, const FusedEpilogue &epi, int lane, EpiParked *queue,
                                                int queue_stride, uint32_t idx_salt = 0, unsigned long long *st = nullptr,
@@ -141,7 +140,6 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
             unsigned long long wave_any = 0ull;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int cb = (e & 3) + 8 * (e >> 2);
                 const float4 qf = qf_of(i, e);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -175,7 +173,7 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
                 if constexpr (!INT_ACC) drop = drop && __builtin_fabsf(a) <= 3.4028234663852886e38f;
                 drop = drop || !has_query || !ok[j];
                 if (!drop) {
-                    if (parked < kEpiQueue) {
+                    if (parked < QDEPTH) {
                         EpiParked pk;
                         pk.a = a; pk.idx = (uint32_t)((i * 16 + e) * NJ + j) + idx_salt;
                         queue[parked * queue_stride] = pk;
@@ -197,7 +195,7 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
     }
     ORR_EPI_STAMP(6);
 #undef ORR_EPI_STAMP
-    if (parked > kEpiQueue) parked = kEpiQueue;
+    if (parked > QDEPTH) parked = QDEPTH;
     for (int s = 0; s < parked; ++s) {
         EpiParked pk = queue[s * queue_stride];
         pk.idx -= idx_salt;

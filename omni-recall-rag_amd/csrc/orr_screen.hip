@@ -44,10 +44,23 @@ namespace orr {
 namespace {
 
 constexpr int kScBM = 256, kScBN = 256, kScBK = 32;
-constexpr int kScImage = kScBM * kScBK * 2;             // bytes of one operand image (16 KiB)
-constexpr int kScStage = 2 * kScImage;                  // A image | B image
-constexpr int kScNS = 5;                                // stages in the ring
-constexpr int kScLds = kScNS * kScStage;                // 160 KiB
+constexpr int kScImage = kScBM * kScBK * 2;             // bytes of one operand image of one K-tile (16 KiB)
+// LDS: a ring of kScNA query images, a ring of kScNB row images, and 32 KiB that belong to the epilogue.  The two rings
+// are separate so that their depths can differ (the rows come from HBM, the queries from L2) and so that a wave
+// requests from ONE ring only (see the kernel).  Measured at 1M x 3072 rows x 256 queries (ORR_SC_NA / ORR_SC_NB builds
+// on one box): row depth 4 = 5 = 6 stages (0.850 / 0.855 / 0.850 ms), query depth 2 instead of 3: 0.905 ms -- the K
+// loop is not waiting for memory; what bounds it is the waves' own instruction streams around the one barrier per
+// K-tile (in-kernel stamps: 1,560 cycles per K-tile against 1,024 of MFMA issue; the first form of the new request
+// code, ~45 scalar instructions per piece, took 2,240).
+#ifndef ORR_SC_NA
+#define ORR_SC_NA 3
+#define ORR_SC_NB 5
+#endif
+constexpr int kScNA = ORR_SC_NA, kScNB = ORR_SC_NB;
+constexpr int kScEpiBytes = 32768;                      // parking queue (7 entries x 8 B x 512 threads) + the tile's query constants (4 KiB)
+constexpr int kScEpiQueue = 7;
+constexpr int kScLds = (kScNA + kScNB) * kScImage + kScEpiBytes;       // 160 KiB
+static_assert(kScLds <= 160 * 1024, "the rings and the epilogue's region must fit a CU's LDS");
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -69,23 +82,30 @@ typedef int i32x16v __attribute__((ext_vector_type(16)));
 // fill the first LIVE <= 4 of them: waves 4..7 (query rows 128..255) then only keep requesting row pieces,
 // waves 0..3 multiply their first LIVE query tiles, the upper half of the query image is never requested
 // (LIVE <= 2: nor its second quarter) -- the kernel turns from latency- into HBM-bound.
-template <bool FUSED, int MODE, bool I8, int LIVE = 8>
+//
+// Who requests what: waves 0..3 the query image (4 / 2 / 1 pieces of 1 KiB each per K-tile for LIVE = 8 / 4 / <= 2),
+// waves 4..7 the row image (4 pieces each).  s_waitcnt vmcnt counts a wave's requests in issue order, so a wave that
+// requested both could not keep five row tiles in flight behind two query tiles; with the roles split every wave
+// waits for exactly the oldest tile of its own ring.
+template <bool FUSED, bool I8, int LIVE = 8>
 __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
                                                              const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
                                                              int32_t D, float *__restrict__ S, int64_t s_stride,
                                                              int32_t n_ntiles, int32_t n_mtiles, int32_t flags, FusedEpilogue epi)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const lds_a = lds, *const lds_b = lds + kScNA * kScImage, *const lds_epi = lds + (kScNA + kScNB) * kScImage;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     constexpr int LI = LIVE >= 4 ? 4 : LIVE;                               // query tiles a multiplying wave owns
     const bool active = LIVE == 8 || wr == 0;
-    constexpr int kPiecesActive = LIVE == 8 ? 4 : 3, kPiecesIdle = LIVE <= 2 ? 2 : 3;
+    const bool row_loader = wr != 0;                                        // waves 4..7 request rows, waves 0..3 queries
+    constexpr int kPA = LIVE == 8 ? 4 : LIVE == 4 ? 2 : 1;                  // query pieces per K-tile and requesting wave
+    constexpr int kPB = 4;                                                  // row pieces per K-tile and requesting wave
     // PERSISTENT: a workgroup walks the output tiles id = blockIdx.x, + gridDim.x, ... (the launcher starts one per
-    // CU).  The ring of K-tiles runs on across output tiles: while the last K-tiles of one are multiplied, the
-    // requests that used to be spare copies fetch the first K-tiles of the next, which then arrive during the
-    // epilogue (whose parking queue lives in the one stage that is free at that point).
+    // CU).  The rings run on across output tiles: while the last K-tiles of one are multiplied, the requests fetch
+    // the first K-tiles of the next, which then arrive during the epilogue.
     // ids that differ by 8 share an XCD; the query tiles of one row tile are consecutive there
     const int total_ids = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     auto valid_from = [&](int id) {                                         // first id >= the given one (in this workgroup's walk) with a row tile
@@ -94,47 +114,72 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     };
     const int T = I8 ? D / 64 : D / kScBK;
     const bool stream_rows = n_mtiles == 1 && (flags & 1);
-    // fragment addresses: row = tile row + (lane & 31), chunk = 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3)
     const int fr = lane & 31, fh = lane >> 5;
-    // ONE per-lane value addresses every fragment (read_frag): row = tile row + (lane & 31), 16-byte slot = chunk ^ ((row >> 2) & 3)
-    // with chunk = 2 ks + (lane >> 5); ks = 1 flips bit 5 of the address, the B fragments lie a wave-uniform distance behind
-    const int b_delta = kScImage + (wc * 64 - wr * 128) * 64;
-    const uint32_t lane_off = (uint32_t)(wave * 1024 + lane * 16);
-    int ring0 = 0;                                                          // stage of this output tile's K-tile 0
+    // ---- this wave's request stream.  It runs AHEAD of the multiplication by the depth of its ring and on across output
+    // tiles, so it keeps its own position: (s_id, s_k) = output tile and K-tile requested next, s_src = global address of
+    // this wave's part of that K-tile's image (rows: KiB 4 w .. 4 w + 3 of the row image; queries: kPA KiB of the query
+    // image), s_lds = LDS byte address of the same part in the ring stage it goes to.  A request is three instructions
+    // (M0, a wait state, global_load_lds with the piece's KiB as the immediate offset, which applies to both addresses);
+    // advancing the stream a handful of scalar ones.  (The first form of this loop recomputed stage, source and the
+    // end-of-tile cases per piece, ~45 scalar instructions each: the K loop was then bound by the waves' own
+    // instruction streams, 2,240 cycles per K-tile however the memory behaved.)
+    const uint32_t lane_off = (uint32_t)(lane * 16);
+    const uint32_t part_off = row_loader ? (uint32_t)((wave & 3) * kPB * 1024) : (uint32_t)(wave * kPA * 1024);
+    auto stream_src = [&](int sid) -> const unsigned char * {
+        const int smt = (sid >> 3) % n_mtiles, snt = ((sid >> 3) / n_mtiles) * 8 + (sid & 7);
+        return row_loader ? reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + snt) * T) * kScImage + part_off
+                          : reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)smt * T) * kScImage + part_off;
+    };
+    int s_id = valid_from(blockIdx.x), s_k = 0, s_stage = 0;
+    const unsigned char *s_src = s_id < total_ids ? stream_src(s_id) : nullptr;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(row_loader ? lds_b : lds_a) + part_off;     // LDS byte address of this wave's part in stage 0
+    const int ring_n = row_loader ? kScNB : kScNA;
+    // piece `slot` of the stream's current K-tile
+    auto issue_piece = [&](int slot) {
+        if (!row_loader && slot >= kPA) return;
+        const uint32_t m0v = ring_lds + (uint32_t)s_stage * kScImage;
+        const uint64_t src = (uint64_t)(uintptr_t)s_src;
+#define ORR_GLDS(OFF, POLICY) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF POLICY \
+                                           :: "v"(lane_off), "s"(src), "s"(m0v) : "memory")
+        // (M0 is not on the clobber list: the compiler reserves it and loads it itself right before each of its own uses.)
+        // rows are streamed once when the whole batch fits one query tile: non-temporal, so they do not push
+        // the query images (re-read by every workgroup) out of L2
+        if (row_loader && stream_rows) {
+            switch (slot) { case 0: ORR_GLDS(0, " nt"); break; case 1: ORR_GLDS(1024, " nt"); break; case 2: ORR_GLDS(2048, " nt"); break; default: ORR_GLDS(3072, " nt"); }
+        } else {
+            switch (slot) { case 0: ORR_GLDS(0, ""); break; case 1: ORR_GLDS(1024, ""); break; case 2: ORR_GLDS(2048, ""); break; default: ORR_GLDS(3072, ""); }
+        }
+#undef ORR_GLDS
+    };
+    // the stream moves on to its next K-tile (past the last output tile it keeps re-requesting the last K-tile: spare copies
+    // into stages nobody reads any more)
+    auto advance_stream = [&]() {
+        s_stage = s_stage + 1 == ring_n ? 0 : s_stage + 1;
+        if (s_k + 1 < T) { ++s_k; s_src += kScImage; return; }
+        const int nid = valid_from(s_id + gridDim.x);
+        if (nid < total_ids) { s_id = nid; s_k = 0; s_src = stream_src(nid); }
+    };
+    // until this wave's pieces of the tiles that may still be in flight behind the awaited one are all that is outstanding
+    auto await_own = [&](bool first_of_tile) {
+        if (row_loader) {
+            if (!first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPB * (kScNB - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPB * (kScNB - 1)) : "memory");
+        } else {
+            if (!first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPA * (kScNA - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPA * (kScNA - 1)) : "memory");
+        }
+    };
+    int ring_a = 0, ring_b = 0;                                             // stages of the multiplied output tile's K-tile 0 in the two rings
     bool first = true;
     int tile_seq = 0;
 #define ORR_STAMP(k) if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + (k)] = __builtin_amdgcn_s_memtime()
     for (int id = valid_from(blockIdx.x); id < total_ids;) {
     ORR_STAMP(0);
     const int next_id = valid_from(id + gridDim.x);
+    const bool has_next = next_id < total_ids;
     const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
     const int64_t n0 = row_first + (int64_t)nt * kScBN;
     const int b0 = mt * kScBM;
-
-    // tiled operands: K-tile t of this workgroup's query tile / row tile is 16 KiB at base + t * 16 KiB;
-    // piece g of a tile (g < 2: A image, g >= 2: B image) is the KiB (g & 1) * 8 + wave of it
-    // (uniform bases: they live in scalar registers; one per-lane offset serves all of them)
-    const unsigned char *a_src = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)mt * T) * kScImage;
-    const unsigned char *b_src = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nt) * T) * kScImage;
-    // K-tiles T, T+1, ...: the first ones of the next output tile, or (last output tile) spare copies of this one's last
-    const bool has_next = next_id < total_ids;
-    const int nmt = has_next ? (next_id >> 3) % n_mtiles : mt, nnt = has_next ? ((next_id >> 3) / n_mtiles) * 8 + (next_id & 7) : nt;
-    const unsigned char *a_nxt = reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)nmt * T) * kScImage;
-    const unsigned char *b_nxt = reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + nnt) * T) * kScImage;
-    auto issue_piece = [&](int t, int g) {
-        const bool over = t >= T;
-        const int tc = !over ? t : has_next ? t - T : T - 1;
-        const unsigned char *a_from = (over && has_next ? a_nxt : a_src) + lane_off, *b_from = (over && has_next ? b_nxt : b_src) + lane_off;
-        unsigned char *base = lds + ((ring0 + t) % kScNS) * kScStage + wave * 1024 + (g & 1) * 8192 + (g >> 1) * kScImage;
-        if (MODE == 2 || (MODE == 4 && g < 2) || (MODE == 5 && g >= 2)) return;
-        if (LIVE < 8 && g == 1) return;                                     // query rows 128..255: padding nobody reads
-        if (LIVE <= 2 && g == 0 && wr != 0) return;                         // query rows 64..127 likewise (KiB 4..7 of the piece)
-        // rows are streamed once when the whole batch fits one query tile: non-temporal, so they do not push
-        // the query images (re-read by every workgroup) out of L2
-        if (g < 2) glds16<0>(a_from + (int64_t)tc * kScImage + (g & 1) * 8192, base);
-        else if (stream_rows) glds16<2>(b_from + (int64_t)tc * kScImage + (g & 1) * 8192, base);
-        else glds16<0>(b_from + (int64_t)tc * kScImage + (g & 1) * 8192, base);
-    };
 
     typename std::conditional<I8, i32x16v, f32x16>::type acc[LI][2];
 #pragma unroll
@@ -145,18 +190,24 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
     struct Frag { bf16x8 a[LI], b[2]; };
-    auto read_frag = [&](Frag &f, int t, int ks) {
-        // (recomputed from the lane id every time, behind an opaque copy: kept in a register across the K loop it is
-        // the value the compiler spills, and the reload comes with an s_waitcnt vmcnt(0) that drains the ring)
+    int c_a = ring_a, c_b = ring_b;                                         // ring stages of the K-tile whose fragments are read next
+    auto read_frag = [&](Frag &f, int ks) {
+        // fragment addresses: row = tile row + (lane & 31), 16-byte slot = chunk ^ ((row >> 2) & 3) with chunk = 2 ks + (lane >> 5);
+        // ks = 1 flips bit 5 of the address.  (Recomputed from the lane id every time, behind an opaque copy: kept in a
+        // register across the K loop it is the value the compiler spills, and the reload comes with an s_waitcnt vmcnt(0)
+        // that drains the rings.)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int frag = (wr * 128 + (ln & 31)) * 64 + (((ln >> 5) ^ ((ln >> 2) & 3)) << 4);
-        const unsigned char *st = lds + ((ring0 + t) % kScNS) * kScStage + (frag ^ (ks * 32));
+        const int frag = ((ln & 31) * 64 + (((ln >> 5) ^ ((ln >> 2) & 3)) << 4)) ^ (ks * 32);
+        const unsigned char *sa = lds_a + c_a * kScImage + wr * 128 * 64 + frag;
+        const unsigned char *sb = lds_b + c_b * kScImage + wc * 64 * 64 + frag;
 #pragma unroll
-        for (int i = 0; i < LI; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(st + i * 2048);
+        for (int i = 0; i < LI; ++i) f.a[i] = *reinterpret_cast<const bf16x8 *>(sa + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(st + b_delta + j * 2048);
+        for (int j = 0; j < 2; ++j) f.b[j] = *reinterpret_cast<const bf16x8 *>(sb + j * 2048);
     };
+
+    auto next_stage = [&]() { c_a = c_a + 1 == kScNA ? 0 : c_a + 1; c_b = c_b + 1 == kScNB ? 0 : c_b + 1; };
 
 #define ORR_SB __builtin_amdgcn_sched_barrier(0)
 #define ORR_MM(f, i) \
@@ -164,56 +215,60 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     } else if constexpr (I8) { \
     acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[0]), acc[i][0], 0, 0, 0); \
     acc[i][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[1]), acc[i][1], 0, 0, 0); \
-    } else if constexpr (MODE != 1 && MODE != 4 && MODE != 5) { \
+    } else { \
     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[0], acc[i][0], 0, 0, 0); \
-    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[1], acc[i][1], 0, 0, 0); } else { \
-    acc[i][0][0] += (float)f.a[i][0] + (float)f.b[0][0]; acc[i][1][0] += (float)f.a[i][1] + (float)f.b[1][0]; } ORR_SB
+    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[1], acc[i][1], 0, 0, 0); } ORR_SB
     // One K-tile: CUR holds the fragments of tile t (read an iteration ago), NXT receives those of tile t+1.
-    // Counted wait: 4 pieces per tile per thread; behind tile t+1 the tiles t+2 .. t+NS-2 may still be in
-    // flight.  The barrier makes tile t+1 visible and says nobody reads stage (t-1) % NS any more, which
-    // tile t+NS-1 then takes.  Issue order is pinned, and the first MFMAs go out before the next fragments
-    // are requested (the compiler's lgkmcnt(0) ahead of them then only covers reads that completed an
-    // iteration ago).
-    // One LDS-DMA piece per pair of MFMAs in the first half of the tile.  (Measured alternatives, 1M x 3072
-    // rows x 256 queries: all four pieces right after the barrier, or the SIMD's two waves taking the
-    // request half and the multiply half of the period in opposite order: both 5-8 % slower;
-    // s_setprio(1) around every MFMA pair: no gain; a fourth tile in flight instead of the early fragment
-    // reads of tile t+1: 12 % slower; not requesting query pieces past the batch: no change.)
+    // At the top a wave's own pieces of tile t+1 have landed (counted wait: behind them its ring's later tiles stay in
+    // flight) and its own fragment reads of tile t are complete (lgkmcnt: they were issued half an iteration ago); the
+    // barrier then says both for every wave, so tile t+1 is readable and the stages of tile t are free: they take
+    // tiles t + kScNA / t + kScNB.  Issue order is pinned, and the first MFMAs go out before the next fragments are
+    // requested.  One LDS-DMA piece per pair of MFMAs in the first half of the tile.  (Measured alternatives, 1M x 3072
+    // rows x 256 queries, round 1: all pieces right after the barrier, or the SIMD's two waves taking the request half
+    // and the multiply half of the period in opposite order: both 5-8 % slower; s_setprio(1) around every MFMA pair:
+    // no gain.)
 #define ORR_TILE(CUR0, CUR1, NXT0, NXT1, t) \
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesActive * (kScNS - 3)) : "memory"); \
-    issue_piece((t) + kScNS - 1, 0); ORR_SB; \
+    await_own(false); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    issue_piece(0); ORR_SB; \
     ORR_MM(CUR0, 0); \
-    read_frag(NXT0, (t) + 1, 0); ORR_SB; \
-    ORR_MM(CUR0, 1); issue_piece((t) + kScNS - 1, 2); ORR_SB; \
-    ORR_MM(CUR0, 2); issue_piece((t) + kScNS - 1, 1); ORR_SB; \
-    ORR_MM(CUR0, 3); issue_piece((t) + kScNS - 1, 3); ORR_SB; \
+    read_frag(NXT0, 0); ORR_SB; \
+    ORR_MM(CUR0, 1); issue_piece(1); ORR_SB; \
+    ORR_MM(CUR0, 2); issue_piece(2); ORR_SB; \
+    ORR_MM(CUR0, 3); issue_piece(3); advance_stream(); ORR_SB; \
     ORR_MM(CUR1, 0); \
-    read_frag(NXT1, (t) + 1, 1); ORR_SB; \
+    read_frag(NXT1, 1); next_stage(); ORR_SB; \
     ORR_MM(CUR1, 1); ORR_MM(CUR1, 2); ORR_MM(CUR1, 3)
 
-    // prologue: tiles 0 .. NS-2 requested; tile 0 awaited and read
+    // prologue (first output tile of the workgroup only): every stage of this wave's ring requested
+    if (first) {
+        for (int t = 0; t < ring_n; ++t) {
 #pragma unroll
-    for (int t = 0; t < kScNS - 1; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) if (first) issue_piece(t, g);
+            for (int sl = 0; sl < 4; ++sl) issue_piece(sl);
+            advance_stream();
+        }
+    }
     first = false;
+    // tile 0 awaited by its requesters, then visible to everybody
+    await_own(true);
+    asm volatile("s_barrier" ::: "memory");
     if (active) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesActive * (kScNS - 2)) : "memory");
         Frag fa0, fa1, fb0, fb1;
-        read_frag(fa0, 0, 0);
-        read_frag(fa1, 0, 1);
-        for (int t = 0; t < T; t += 2) {                                    // T = D / 32 is even
+        read_frag(fa0, 0);
+        read_frag(fa1, 1);
+        next_stage();
+        for (int t = 0; t < T; t += 2) {                                    // T is even
             ORR_TILE(fa0, fa1, fb0, fb1, t);
             ORR_TILE(fb0, fb1, fa0, fa1, t + 1);
         }
     } else {
-        // waves without queries: the same barriers, their share of the row (and query) pieces, nothing else
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesIdle * (kScNS - 2)) : "memory");
+        // waves without queries: the same barriers, their row pieces, nothing else
         for (int t = 0; t < T; ++t) {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(kPiecesIdle * (kScNS - 3)) : "memory");
-            issue_piece(t + kScNS - 1, 0);
-            issue_piece(t + kScNS - 1, 2);
-            issue_piece(t + kScNS - 1, 3);
+            await_own(false);
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) issue_piece(sl);
+            advance_stream();
         }
     }
 #undef ORR_TILE
@@ -232,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = b0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    if (row < B && col < n_rows && (MODE != 3 || acc[i][j][e] == 1.2345f)) S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
+                    if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
                 }
             }
     } else {
@@ -247,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         asm volatile("" : "+s"(salt));
         // ONE trip to global memory per tile, requested here and awaited behind the barrier: this thread's 8 bytes of the
         // tile's query constants (256 x float4 = 4 KiB, staged in LDS for every wave) and, for the multiplying waves, the
-        // constants and count-plane words of their rows (orr_epilogue.h).  The wait for them is also the wait for the next
+        // constants and count words of their rows (orr_epilogue.h).  The wait for them is also the wait for the next
         // tile's first K-tiles, which were requested before.
         float2 qf_part;
         {
@@ -257,27 +312,25 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         }
         EpiTileLoads<LI, 2> pre;
         if (active) epilogue_issue_loads(pre, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane);
-        // every wave is done with the stage the queue takes over (its fragment reads were consumed by its MFMAs); a bare
-        // barrier: __syncthreads() would also wait for the next output tile's first K-tiles, which are meant to arrive
-        // during the epilogue
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the parking queue of the epilogue and the query constants: the stage of this tile's last K-tile, the only one no request is bound for
-        unsigned char *stage = lds + ((ring0 + T - 1) % kScNS) * kScStage;
-        EpiParked *queue = reinterpret_cast<EpiParked *>(stage) + tid;
-        float4 *qf_lds = reinterpret_cast<float4 *>(stage + kEpiQueueBytes);
+        // the epilogue's own 32 KiB: the parking queue and the query constants (the previous tile's epilogue is long over:
+        // every wave has passed this tile's barriers since)
+        EpiParked *queue = reinterpret_cast<EpiParked *>(lds_epi) + tid;
+        float4 *qf_lds = reinterpret_cast<float4 *>(lds_epi + kScEpiQueue * 8 * 512);
         reinterpret_cast<float2 *>(qf_lds)[tid] = qf_part;
+        // a bare barrier: __syncthreads() would also wait for the next output tile's first K-tiles
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (active) {
-            unsigned long long *st = (FUSED && epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
+            unsigned long long *st = (epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
             // (integer dots go in as they are: |I| <= 3072 * 127^2, the conversion inside costs at most 2^-24)
-            fused_epilogue<LI, 2, true, typename std::conditional<I8, i32x16v, f32x16>::type, true>(
+            fused_epilogue<LI, 2, true, typename std::conditional<I8, i32x16v, f32x16>::type, true, kScEpiQueue>(
                 acc, b0 + wr * 128, n0 + wc * 64, B, n_rows, ep, lane, queue, 512, salt, st, &pre, qf_lds + wr * 128);
         }
     }
     ORR_STAMP(2);
     if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     ++tile_seq;
-    ring0 = (ring0 + T) % kScNS;
+    ring_a = (ring_a + T) % kScNA;
+    ring_b = (ring_b + T) % kScNB;
     id = next_id;
     }
 #undef ORR_STAMP
@@ -686,7 +739,7 @@ __global__ __launch_bounds__(256) void i8_tile_queries_kernel(const int8_t *__re
 // k_tiles = K-tiles per output tile (D / 64 for int8, D / 32 for bf16).
 static int64_t screen_grid(int64_t tiles, int32_t k_tiles)
 {
-    if (k_tiles < kScNS - 1) return tiles;    // the requests of a tile reach kScNS - 1 K-tiles ahead: never past the next output tile
+    if (k_tiles < kScNB) return tiles;        // the requests of a tile reach kScNB K-tiles ahead: never past the next output tile
     static const int64_t per_launch = [] {
         const char *e = getenv("ORR_SCREEN_PERSIST");
         if (e && atoi(e) == 0) return (int64_t)0;
@@ -718,7 +771,6 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
-    static const int live_max = [] { const char *e = getenv("ORR_SCREEN_LIVE"); return e ? atoi(e) : 0; }();   // 8: always the full tile
     // ORR_SCREEN_STAMPS=file (diagnostic): every launch appends its workgroups' per-tile phase stamps to the file
     static const char *stamp_path = getenv("ORR_SCREEN_STAMPS");
     static unsigned long long *d_stamps = nullptr;
@@ -731,13 +783,13 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     }
     const FusedEpilogue &epi_use = epi_st;
 #define ORR_LAUNCH_I8(L) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, true, L>), \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, true, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
+        hipLaunchKernelGGL((screen_bf16_kernel<true, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
-    if (live_max == 8 || B > 128) ORR_LAUNCH_I8(8);
+    if (B > 128) ORR_LAUNCH_I8(8);
     else if (B > 64) ORR_LAUNCH_I8(4);
     else if (B > 32) ORR_LAUNCH_I8(2);
     else ORR_LAUNCH_I8(1);
@@ -762,10 +814,10 @@ hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_t
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const FusedEpilogue none{};
 #define ORR_LAUNCH_I8D(L) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<false, 0, true, L>), \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<false, true, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<false, 0, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
+        hipLaunchKernelGGL((screen_bf16_kernel<false, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, 0, none); } while (0)
     if (B > 128) ORR_LAUNCH_I8D(8);
@@ -879,36 +931,21 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const __bf16 *q_hi = static_cast<const __bf16 *>(q_tiled), *eh = static_cast<const __bf16 *>(e_shadow);
     const FusedEpilogue none{};
-    // ORR_SCREEN_MODE (diagnostic, dots-to-S form only): 1 no MFMA, 2 no LDS-DMA, 3 no stores,
-    // 4 no MFMA and no query pieces, 5 no MFMA and no row pieces
-    static const int mode = [] { const char *e = getenv("ORR_SCREEN_MODE"); return e ? atoi(e) : 0; }();
     static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
-#define ORR_LAUNCH(F, M, E) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, M, false>), \
+#define ORR_LAUNCH_LIVE(F, L, E) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, false, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<F, M, false>), dim3((unsigned)screen_grid(blocks, D / kScBK)), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
+        hipLaunchKernelGGL((screen_bf16_kernel<F, false, L>), dim3((unsigned)screen_grid(blocks, D / kScBK)), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, E); } while (0)
-    static const int live_max = [] { const char *e = getenv("ORR_SCREEN_LIVE"); return e ? atoi(e) : 0; }();   // 8: always the full tile
-#define ORR_LAUNCH_LIVE(L) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, 0, false, L>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
-        if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_bf16_kernel<true, 0, false, L>), dim3((unsigned)screen_grid(blocks, D / kScBK)), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
-                           S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, *epi); } while (0)
     if (epi) {
-        if (live_max == 8 || B > 128) ORR_LAUNCH_LIVE(8);
-        else if (B > 64) ORR_LAUNCH_LIVE(4);
-        else if (B > 32) ORR_LAUNCH_LIVE(2);
-        else ORR_LAUNCH_LIVE(1);
+        if (B > 128) ORR_LAUNCH_LIVE(true, 8, *epi);
+        else if (B > 64) ORR_LAUNCH_LIVE(true, 4, *epi);
+        else if (B > 32) ORR_LAUNCH_LIVE(true, 2, *epi);
+        else ORR_LAUNCH_LIVE(true, 1, *epi);
+    } else {
+        ORR_LAUNCH_LIVE(false, 8, none);
     }
-    else if (mode == 1) ORR_LAUNCH(false, 1, none);
-    else if (mode == 2) ORR_LAUNCH(false, 2, none);
-    else if (mode == 3) ORR_LAUNCH(false, 3, none);
-    else if (mode == 4) ORR_LAUNCH(false, 4, none);
-    else if (mode == 5) ORR_LAUNCH(false, 5, none);
-    else ORR_LAUNCH(false, 0, none);
-#undef ORR_LAUNCH
 #undef ORR_LAUNCH_LIVE
     return hipGetLastError();
 }
