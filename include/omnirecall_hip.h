@@ -237,6 +237,11 @@ int64_t orr_index_live_rows(const orr_index *idx);
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "dead_rows_before"  deleted rows in the shards in front of this one (default 0), see above.
+ *   "shard_pass"     0/1/2 (default 0): which pass orr_search_shard runs -- 0 the library's choice, 1 the unfused
+ *                    batched pass, 2 the reference-arithmetic pass over every row.  The caller of
+ *                    orr_merge_candidates sets 2 for the repeat of a batch some query of which could not be certified.
+ *   "shard_topk"     the caller's topK for orr_search_shard (default 0: unknown).  When set, the two-stage pass takes its
+ *                    floor from the k-th best score of the sampled prefix instead of the k'-th: fewer survivors.
  *   "fuse_epilogue"  0/1 (default 0): batches > 64 queries over >= 196,608 rows score and filter
  *                    inside the GEMM epilogue instead of writing the dots to HBM.
  *   "two_stage"      0/1/2 (default 1): searches over >= 196,608 rows screen ALL rows with ONE low-precision
@@ -261,6 +266,39 @@ int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets
 int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap);  /* returns count */
 
 int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset);  /* out may be NULL (reset only) */
+
+/* ---- several GPUs behind one handle, in ONE process ------------------------------
+ * The reference host is a single process with a singleton store (Program.cs:59,
+ * IngestionServiceCollectionExtensions.cs:22-23); north_star keeps that host in C#.  An orr_cluster owns one
+ * shard per entry of `devices` (the same ordinal may appear twice: two shards on one GPU) and answers
+ * orr_cluster_search_batch exactly as one orr_index over all the rows would: every shard scores the whole batch on
+ * its own device at once (one host thread per shard), the per-shard [B][k'+1] candidate records come back through
+ * pinned host memory, the host merges and certifies them as orr_merge_candidates does and repeats only the queries
+ * that could not be certified.  (Between PROCESSES the same records travel by one RCCL all-gather: sharded.py.)
+ *   create            dim as in orr_config; capacity_rows_per_shard reserves device memory per shard (0: grow).
+ *   shard(i)          borrowed handle for orr_index_append / orr_index_set_option / orr_index_delete_rows.  Shard i
+ *                     must receive rows that are all at least as new as every row of shard i + 1 (partition the
+ *                     store's rows by CreatedAtUtc, newest first; orr_cluster_seal checks it): the global candidate
+ *                     order (InMemoryIngestionStore.cs:61) is then shard 0's rows, shard 1's, ...
+ *   seal              seals every shard (concurrently) and places them in the global order (row_base).
+ *   search_batch      arguments as orr_search_batch; q must be HOST memory (each device uploads it).  Row ids are
+ *                     the ids given at append (default: position in the shard + its row_base at append time, i.e.
+ *                     pass explicit row_ids when appending to a cluster).
+ * Not thread-safe against itself: one search at a time per cluster (searches on different clusters are independent). */
+typedef struct orr_cluster orr_cluster;
+int        orr_cluster_create(const int32_t *devices, int32_t n_shards, int32_t dim, int64_t capacity_rows_per_shard,
+                              orr_cluster **out);
+void       orr_cluster_destroy(orr_cluster *c);
+int32_t    orr_cluster_shards(const orr_cluster *c);
+orr_index *orr_cluster_shard(orr_cluster *c, int32_t i);
+int        orr_cluster_seal(orr_cluster *c);
+int64_t    orr_cluster_rows(const orr_cluster *c);
+int        orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, const float *q_host,
+                                    const uint8_t *terms_utf8, const uint32_t *term_off,
+                                    const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+                                    int64_t candidate_limit, int64_t *out_rows, double *out_scores,
+                                    int32_t *out_counts);
+int        orr_cluster_search_stats(orr_cluster *c, orr_search_stats *out, int32_t reset);
 
 #ifdef __cplusplus
 }

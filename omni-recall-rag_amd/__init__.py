@@ -10,9 +10,9 @@ directory name is not a valid Python identifier, so load it through
 """
 from . import _native as native
 from ._native import OrrError
-from .index import CAND_DTYPE, MicroBatcher, PackedTerms, RecallIndex, merge_candidates, pack_contents, pack_terms
+from .index import CAND_DTYPE, MicroBatcher, PackedTerms, RecallCluster, RecallIndex, merge_candidates, pack_contents, pack_terms
 from . import text
 from . import service
 
-__all__ = ["native", "OrrError", "RecallIndex", "MicroBatcher", "merge_candidates", "pack_contents", "pack_terms", "PackedTerms", "text", "service",
+__all__ = ["native", "OrrError", "RecallIndex", "RecallCluster", "MicroBatcher", "merge_candidates", "pack_contents", "pack_terms", "PackedTerms", "text", "service",
            "CAND_DTYPE"]

@@ -102,6 +102,22 @@ hip.orr_index_kernel_stats.restype = C.c_int
 hip.orr_index_kernel_stats.argtypes = [_vp, _vp, _i32]
 hip.orr_index_search_stats.restype = C.c_int
 hip.orr_index_search_stats.argtypes = [_vp, C.POINTER(OrrSearchStats), _i32]
+hip.orr_cluster_create.restype = C.c_int
+hip.orr_cluster_create.argtypes = [_vp, _i32, _i32, _i64, C.POINTER(_vp)]
+hip.orr_cluster_destroy.restype = None
+hip.orr_cluster_destroy.argtypes = [_vp]
+hip.orr_cluster_shards.restype = _i32
+hip.orr_cluster_shards.argtypes = [_vp]
+hip.orr_cluster_shard.restype = _vp
+hip.orr_cluster_shard.argtypes = [_vp, _i32]
+hip.orr_cluster_seal.restype = C.c_int
+hip.orr_cluster_seal.argtypes = [_vp]
+hip.orr_cluster_rows.restype = _i64
+hip.orr_cluster_rows.argtypes = [_vp]
+hip.orr_cluster_search_batch.restype = C.c_int
+hip.orr_cluster_search_batch.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]
+hip.orr_cluster_search_stats.restype = C.c_int
+hip.orr_cluster_search_stats.argtypes = [_vp, C.POINTER(OrrSearchStats), _i32]
 
 host.orrh_is_blank.restype = _i32
 host.orrh_is_blank.argtypes = [C.c_char_p, _i64]
@@ -169,6 +185,8 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
     "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_view",
     "orr_index_delete_rows", "orr_index_live_rows", "orr_index_search_stats",
+    "orr_cluster_create", "orr_cluster_destroy", "orr_cluster_shards", "orr_cluster_shard", "orr_cluster_seal", "orr_cluster_rows",
+    "orr_cluster_search_batch", "orr_cluster_search_stats",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",

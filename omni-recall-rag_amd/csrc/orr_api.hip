@@ -173,6 +173,8 @@ struct orr_index {
     bool opt_fuse_epilogue = false;
     int opt_two_stage = 1;             // 0 off, 1 on (bf16 shadow when it fits), 2 on without the shadow
     int opt_shard_pass = 0;            // orr_search_shard: 0 the library picks the pass, 1 unfused batched pass, 2 exact pass
+    int opt_shard_topk = 0;            // orr_search_shard: the caller's topK when > 0 (the two-stage floor then comes from the k-th best, not the k'-th)
+    int sample_boost = 1;              // two-stage pass: the sampled prefix is this many times the default (1..16), steered by the survivors measured
     DevBuf emb_shadow;                 // bf16(E), [n_rows][dim]: operand of the screening GEMM (two-stage pass)
     bool shadow_ready = false, shadow_failed = false;
     DevBuf emb_i8, i8_scale, i8_rel_err, i8_rel_hat, i8_rowf;   // int8 shadow: streaming screen of 1..4 queries (K2i), screening GEMM (K2j)
@@ -1070,6 +1072,11 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
         idx->dead_before = value;
         return ORR_OK;
     }
+    if (strcmp(name, "shard_topk") == 0) {
+        if (value < 0 || value > 1 << 30) return fail(ORR_EINVAL, "orr_index_set_option: shard_topk must be >= 0");
+        idx->opt_shard_topk = (int)value;
+        return ORR_OK;
+    }
     if (strcmp(name, "shard_pass") == 0) {
         if (value < 0 || value > 2) return fail(ORR_EINVAL, "orr_index_set_option: shard_pass takes 0, 1 or 2");
         idx->opt_shard_pass = (int)value;
@@ -1199,6 +1206,7 @@ struct BatchArgs {
     bool force_exact = false;      // skip the MFMA candidate pass (escalation after a failed certificate)
     mutable bool used_mfma = false; // set by run_shard
     bool no_fuse = false;          // keep the batched pass unfused (retry after a candidate-buffer overflow)
+    const double *norms_host = nullptr; // exact normA of every query, already computed by the caller (orr_cluster: once for all shards)
     orr_candidate *out_dev = nullptr;   // orr_search_shard with a device-resident `out`: the kernels write the records there
     mutable bool used_fused = false;
     mutable bool used_two_stage = false;   // the pass kept survivors in per-query buffers (idx->h_survivors holds their counts)
@@ -1251,13 +1259,19 @@ bool is_device_pointer(const void *p)
 // 1024 queries, 4 / 16 / 64 segments = 84.3 / 86.8 / 95.4 ms; the re-score stays below 0.4 ms throughout.
 // The streaming form (1..8 queries) re-scores in parallel waves whose time does not grow with the number
 // of survivors, so it goes down to two segments.
-static int32_t sample_segments(int32_t n_seg_all, int64_t n, int32_t k, bool small_batch)
+// boost (1..16, orr_index::sample_boost): scores without steps (cosine-only queries: config C4) leave 10..50 times as
+// many survivors as hybrid ones, because the int8 bound is then comparable to the spacing of the scores around the
+// floor; the index doubles the sample while the measured survivors per query stay above 4096 and halves it again
+// below 512 (12.5M rows, 256 cosine-only queries, k' = 32: 16,000 survivors per query and 10 ms of exact re-scoring
+// with the default sample of 200k rows against 14 ms for the screen itself; four times the sample, a quarter of both).
+static int32_t sample_segments(int32_t n_seg_all, int64_t n, int32_t k, bool small_batch, int boost)
 {
     static const int forced = [] { const char *e = getenv("ORR_TS_SAMPLE_SEGS"); return e ? atoi(e) : 0; }();
     if (forced > 0) return std::min<int32_t>(forced, n_seg_all);
-    const int64_t rows = (int64_t)std::max<int32_t>(1, k) * n / 2000;
+    const int64_t rows = (int64_t)std::max<int32_t>(1, k) * n / 2000 * std::max(1, boost);
     const int64_t segs = (rows + orr::kSelSegRows - 1) / orr::kSelSegRows;
-    return (int32_t)std::min<int64_t>(64, std::max<int64_t>(small_batch ? 2 : 4, segs));
+    const int64_t most = std::min<int64_t>(64 * (int64_t)std::max(1, boost), std::max<int64_t>(n_seg_all / 8, 4));   // never more than an eighth of the rows
+    return (int32_t)std::min<int64_t>(most, std::max<int64_t>(small_batch ? 2 : 4, segs));
 }
 
 // ORR_HOST_TIMING=1: where the host side of a search spends its time, printed to stderr every 64 calls (diagnostic,
@@ -1360,7 +1374,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (use_cos) {
         const size_t qbytes = sizeof(float) * (size_t)B * a.dim;
         static const int dev_norm_min = [] { const char *e = getenv("ORR_DEV_NORMS_MIN_BATCH"); return e ? atoi(e) : 16; }();
-        if (is_device_pointer(a.q) && kprime <= orr::kSelWidth && B >= dev_norm_min) {
+        if (is_device_pointer(a.q) && kprime <= orr::kSelWidth && B >= dev_norm_min && !a.norms_host) {
             // (a handful of queries: the download and the host's pass cost less than the kernel's 3072-step chains)
             d_q = a.q;
             dev_norms = true;
@@ -1558,7 +1572,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
             ts_gemv = true;
             two_stage = true;
             const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
-            fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true);
+            fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true, idx->sample_boost);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
             if (ts_i8) {
                 ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
@@ -1589,7 +1603,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                 const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
                 two_stage = idx->opt_two_stage != 0 && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
                 fused_sample_seg = ((idx->opt_fuse_epilogue || two_stage) && !a.no_fuse && n_seg_all >= 48)
-                                       ? sample_segments(n_seg_all, n, a.topk, false) : 0;
+                                       ? sample_segments(n_seg_all, n, a.topk, false, idx->sample_boost) : 0;
                 dotf_rows = fused_sample_seg > 0 ? (int64_t)fused_sample_seg * orr::kSelSegRows : n;
                 ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)dotf_rows));
                 d_dotf = idx->ws_dotf.as<float>();
@@ -1652,7 +1666,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     ORR_TRY(idx->pin_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     ORR_TRY(idx->ws_qc.reserve(sizeof(orr::QueryConst) * (size_t)B));
     orr::QueryConst *qc = idx->pin_qc.as<orr::QueryConst>();
-    if (use_cos && !dev_norms) exact_norms(idx->pin_q.as<float>(), B, a.dim, idx->h_norm_a.data());
+    if (use_cos && !dev_norms) {
+        if (a.norms_host) memcpy(idx->h_norm_a.data(), a.norms_host, sizeof(double) * (size_t)B);
+        else exact_norms(idx->pin_q.as<float>(), B, a.dim, idx->h_norm_a.data());
+    }
     for (int32_t b = 0; b < B; ++b) {
         qc[b].use_cos = use_cos ? 1 : 0;
         qc[b].norm_a = idx->h_norm_a[(size_t)b];
@@ -1951,7 +1968,14 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         idx->bitmaps_clean = std::max(bm_bytes, bm_clean_before);
     }
     if (dev_norms) memcpy(idx->h_norm_a.data(), idx->pin_norm.p, sizeof(double) * (size_t)B);
-    if (a.used_two_stage) idx->h_survivors.assign(idx->pin_cnt.as<uint32_t>(), idx->pin_cnt.as<uint32_t>() + B);
+    if (a.used_two_stage) {
+        idx->h_survivors.assign(idx->pin_cnt.as<uint32_t>(), idx->pin_cnt.as<uint32_t>() + B);
+        uint64_t sum = 0;
+        for (uint32_t cnt : idx->h_survivors) sum += cnt;
+        const uint64_t mean = sum / (uint64_t)B;
+        if (mean > 4096 && idx->sample_boost < 16) idx->sample_boost *= 2;
+        else if (mean < 512 && idx->sample_boost > 1) idx->sample_boost /= 2;
+    }
     g_ht.mark(4);
     collect_events(idx);
     if (kw_overflow_possible) {
@@ -2266,13 +2290,53 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     // the caller's escalation after a merge that could not certify every query (orr_merge_candidates)
     a.no_fuse = idx->opt_shard_pass >= 1;
     a.force_exact = idx->opt_shard_pass >= 2;
-    if (is_device_pointer(out)) {               // records written where the caller wants them (the all-gather's send buffer)
-        a.out_dev = out;
-        ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
-        return ORR_OK;
-    }
+    // the floor of the two-stage pass: from the k-th best of the sample when the caller told its topK (valid across shards:
+    // the global k-th best is at least every shard's), else from the k'-th
+    if (idx->opt_shard_topk > 0) a.topk = std::min<int32_t>(kprime, idx->opt_shard_topk);
+    const bool dev_out = is_device_pointer(out);
+    const size_t rec_q = sizeof(orr_candidate) * ((size_t)kprime + 1);
+    if (dev_out) a.out_dev = out;               // records written where the caller wants them (the all-gather's send buffer)
     ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
-    HIP_TRY(hipMemcpy(out, idx->ws_cand.p, sizeof(orr_candidate) * (size_t)B * ((size_t)kprime + 1), hipMemcpyDefault));
+    if (!dev_out) HIP_TRY(hipMemcpy(out, idx->ws_cand.p, rec_q * (size_t)B, hipMemcpyDefault));
+    idx->sstats.searches += 1; idx->sstats.queries += B; idx->sstats.passes += 1;
+    // Survivors' buffers that overflowed (clustered rows, cosine-only scores): THOSE queries again, here, with buffers sized
+    // from the measured counts -- a caller that only sees ORR_CAND_OVERFLOW could but repeat the whole batch through the
+    // exact pass on every shard.
+    const int64_t n = participating_rows(idx, candidate_limit);
+    for (int round = 0; round < 4 && a.used_two_stage && (int32_t)idx->h_survivors.size() == B; ++round) {
+        std::vector<int32_t> over;
+        uint32_t worst = 0;
+        for (int32_t b = 0; b < B; ++b) {
+            const uint32_t cnt = idx->h_survivors[(size_t)b];
+            idx->sstats.survivors_total += cnt; idx->sstats.survivor_samples += 1;
+            if ((int64_t)cnt > idx->sstats.survivors_max) idx->sstats.survivors_max = cnt;
+            if (cnt > idx->pass_cap) { over.push_back(b); worst = std::max(worst, cnt); }
+        }
+        if (over.empty()) break;
+        idx->sstats.overflowed_queries += (int64_t)over.size();
+        if (worst >= (1u << 19) || (int64_t)worst * 2 >= n || over.size() * (size_t)worst * 96 >= ((size_t)2 << 30)) break;   // the caller's escalation
+        uint32_t cap = idx->pass_cap;
+        while (cap < worst + worst / 8) cap *= 2;
+        if (cap > idx->survivor_cap) idx->survivor_cap = cap;
+        idx->sstats.buffer_growths += 1;
+        SubBatch sb;
+        BatchArgs sub;
+        a.out_dev = nullptr;
+        ORR_TRY(build_subset(idx, a, over, sb, sub));
+        sub.no_fuse = a.no_fuse; sub.force_exact = a.force_exact;
+        ORR_TRY(run_shard(idx, sub, kprime, false, nullptr, nullptr));          // records in idx->ws_cand
+        idx->sstats.passes += 1; idx->sstats.requeried += (int64_t)over.size();
+        for (size_t i = 0; i < over.size(); ++i)
+            HIP_TRY(hipMemcpy(reinterpret_cast<unsigned char *>(out) + rec_q * (size_t)over[i],
+                              static_cast<const unsigned char *>(idx->ws_cand.p) + rec_q * i, rec_q, hipMemcpyDefault));
+        if (!sub.used_two_stage || idx->h_survivors.size() != over.size()) break;
+        // the counts of the repeated queries, back in the batch's numbering, for the next round's check
+        std::vector<uint32_t> merged((size_t)B, 0u);
+        for (size_t i = 0; i < over.size(); ++i) merged[(size_t)over[i]] = idx->h_survivors[i];
+        idx->h_survivors.swap(merged);
+        a.used_two_stage = true;
+    }
+    idx->sstats.survivor_capacity = idx->survivor_cap;
     return ORR_OK;
 }
 
@@ -2311,6 +2375,259 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     const int r = search_ids(idx, a, all, true, kprime, n, out_rows, out_scores, out_counts, 0);
     g_ht.done();
     return r;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// orr_cluster: several shards behind ONE handle in ONE process (the reference host is a single process: Program.cs:59,
+// IngestionServiceCollectionExtensions.cs:22-23).  Shard i lives on devices[i] and holds a contiguous range of the global
+// candidate order (rows of shard i are all at least as new as those of shard i + 1).  A search runs orr_search_shard's
+// device side on every shard at once (one host thread per shard, each bound to its device), the [B][k'+1] records of
+// every shard come back through pinned host memory, and the host finishes all queries exactly as orr_merge_candidates
+// does -- the record exchange of the multi-process path (RCCL all-gather, sharded.py) without the collective, because
+// here every record is wanted in ONE address space.  Escalation is per query, as in orr_search_batch.
+// ---------------------------------------------------------------------------------------------------------------------
+struct orr_cluster {
+    std::vector<orr_index *> shards;
+    int32_t dim = 0;
+    bool sealed = false;
+    std::mutex mu;
+    orr_search_stats sstats{};
+};
+
+namespace {
+
+// fn(i) for every shard, one thread each (the calling thread takes shard 0); returns the first failure
+int for_each_shard(int32_t n, const std::function<int(int32_t)> &fn)
+{
+    std::vector<int> rc((size_t)n, ORR_OK);
+    std::vector<std::string> msg((size_t)n);
+    std::vector<std::thread> th;
+    for (int32_t i = 1; i < n; ++i)
+        th.emplace_back([&, i] { rc[(size_t)i] = fn(i); if (rc[(size_t)i] != ORR_OK) msg[(size_t)i] = g_last_error; });
+    rc[0] = fn(0);
+    if (rc[0] != ORR_OK) msg[0] = g_last_error;
+    for (auto &t : th) t.join();
+    for (int32_t i = 0; i < n; ++i)
+        if (rc[(size_t)i] != ORR_OK) { g_last_error = msg[(size_t)i]; return rc[(size_t)i]; }     // (the detail was set on that shard's thread)
+    return ORR_OK;
+}
+
+int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<int32_t> &ids, bool whole, int64_t kprime, int64_t n_total,
+                       int64_t *out_rows, double *out_scores, int32_t *out_counts, int depth)
+{
+    const int32_t nb = (int32_t)ids.size(), G = (int32_t)c->shards.size();
+    const int32_t take = std::max<int32_t>(1, orig.topk);
+    const bool use_cos = orig.dim > 0 && orig.dim == c->dim;
+    int64_t n_max = 1;
+    for (orr_index *sh : c->shards) n_max = std::max<int64_t>(n_max, participating_rows(sh, orig.candidate_limit));
+    if ((orig.no_fuse || orig.force_exact) && nb > 1 && (size_t)nb * (size_t)n_max * 8 > kPassWorkspaceBytes) {
+        const int32_t per = (int32_t)std::max<size_t>(1, kPassWorkspaceBytes / ((size_t)n_max * 8));
+        for (int32_t i0 = 0; i0 < nb; i0 += per) {
+            std::vector<int32_t> part(ids.begin() + i0, ids.begin() + std::min<int32_t>(nb, i0 + per));
+            ORR_TRY(cluster_search_ids(c, orig, part, false, kprime, n_total, out_rows, out_scores, out_counts, depth));
+        }
+        return ORR_OK;
+    }
+    // the sub-batch in host memory (the cluster's queries are host-resident by contract), built once for all shards
+    SubBatch sb;
+    BatchArgs cur = orig;
+    if (!whole) ORR_TRY(build_subset(c->shards[0], orig, ids, sb, cur));
+    std::vector<double> norms;
+    if (use_cos) {
+        norms.resize((size_t)nb);
+        exact_norms(cur.q, nb, cur.dim, norms.data());
+        cur.norms_host = norms.data();
+    }
+    const size_t rec_per_shard = (size_t)nb * ((size_t)kprime + 1);
+    std::vector<orr_candidate> all((size_t)G * rec_per_shard);
+    std::vector<uint8_t> used_two_stage((size_t)G, 0), used_fused((size_t)G, 0), used_mfma((size_t)G, 0);
+    ORR_TRY(for_each_shard(G, [&](int32_t g) -> int {
+        orr_index *sh = c->shards[(size_t)g];
+        std::lock_guard<std::mutex> lock(sh->mu);
+        BatchArgs mine = cur;
+        const float *qh = nullptr;
+        const orr_candidate *recs = nullptr;
+        ORR_TRY(run_shard(sh, mine, (int32_t)kprime, true, &qh, &recs));
+        if (recs) memcpy(all.data() + (size_t)g * rec_per_shard, recs, sizeof(orr_candidate) * rec_per_shard);
+        else HIP_TRY(hipMemcpy(all.data() + (size_t)g * rec_per_shard, sh->ws_cand.p, sizeof(orr_candidate) * rec_per_shard, hipMemcpyDeviceToHost));
+        used_two_stage[(size_t)g] = mine.used_two_stage; used_fused[(size_t)g] = mine.used_fused; used_mfma[(size_t)g] = mine.used_mfma;
+        return ORR_OK;
+    }));
+    c->sstats.passes += 1;
+    if (depth > 0) c->sstats.requeried += nb;
+    std::vector<uint8_t> cert((size_t)nb, 1);
+    int32_t unc = 0;
+    std::vector<int64_t> rows((size_t)nb * take);
+    std::vector<double> scores((size_t)nb * take);
+    std::vector<int32_t> counts((size_t)nb);
+    ORR_TRY(merge_impl(G, nb, (int32_t)kprime, all.data(), cur.dim, use_cos, cur.q, use_cos ? norms.data() : nullptr, cur.query_term_off,
+                       cur.now_ticks, cur.topk, rows.data(), scores.data(), counts.data(), &unc, cert.data()));
+    for (int32_t i = 0; i < nb; ++i) {                                      // (a later pass overwrites what could not be certified)
+        const size_t b = (size_t)ids[(size_t)i];
+        memcpy(out_rows + b * take, rows.data() + (size_t)i * take, sizeof(int64_t) * take);
+        memcpy(out_scores + b * take, scores.data() + (size_t)i * take, sizeof(double) * take);
+        if (out_counts) out_counts[b] = counts[(size_t)i];
+    }
+    // survivors of the screening pass, per shard: statistics, and the buffer size a repeat needs
+    bool any_fused = false, any_mfma = false, grow = false, only_overflow = unc > 0;
+    for (int32_t g = 0; g < G; ++g) {
+        orr_index *sh = c->shards[(size_t)g];
+        any_fused = any_fused || used_fused[(size_t)g];
+        any_mfma = any_mfma || used_mfma[(size_t)g];
+        if (!used_two_stage[(size_t)g] || (int32_t)sh->h_survivors.size() != nb) continue;
+        uint32_t worst = 0;
+        for (int32_t i = 0; i < nb; ++i) {
+            const uint32_t cnt = sh->h_survivors[(size_t)i];
+            c->sstats.survivors_total += cnt;
+            if ((int64_t)cnt > c->sstats.survivors_max) c->sstats.survivors_max = cnt;
+            if (cnt > sh->pass_cap) { c->sstats.overflowed_queries += 1; if (!cert[(size_t)i]) worst = std::max(worst, cnt); }
+        }
+        c->sstats.survivor_samples += nb;
+        if (worst > 0 && worst < (1u << 19) && (int64_t)worst * 2 < participating_rows(sh, orig.candidate_limit) &&
+            (size_t)unc * (size_t)worst * 96 < ((size_t)2 << 30)) {
+            uint32_t cap = sh->pass_cap;
+            while (cap < worst + worst / 8) cap *= 2;
+            if (cap > sh->survivor_cap) { sh->survivor_cap = cap; grow = true; }
+        } else if (worst > 0) {
+            only_overflow = false;                                          // too many survivors to buffer: a more exact pass instead
+        }
+        c->sstats.survivor_capacity = std::max<int64_t>(c->sstats.survivor_capacity, sh->survivor_cap);
+    }
+    if (unc == 0) return ORR_OK;
+    // queries uncertified for a reason other than an overflowing buffer need a more exact pass whatever the buffers do
+    if (grow) {
+        for (int32_t g = 0; g < G && only_overflow; ++g) {
+            orr_index *sh = c->shards[(size_t)g];
+            if (!used_two_stage[(size_t)g] || (int32_t)sh->h_survivors.size() != nb) { only_overflow = false; break; }
+        }
+        if (only_overflow)
+            for (int32_t i = 0; i < nb && only_overflow; ++i) {
+                if (cert[(size_t)i]) continue;
+                bool over = false;
+                for (int32_t g = 0; g < G; ++g) over = over || c->shards[(size_t)g]->h_survivors[(size_t)i] > c->shards[(size_t)g]->pass_cap;
+                only_overflow = over;
+            }
+    }
+    std::vector<int32_t> again;
+    for (int32_t i = 0; i < nb; ++i) if (!cert[(size_t)i]) again.push_back(ids[(size_t)i]);
+    BatchArgs next = orig;
+    if (grow && only_overflow) {
+        c->sstats.buffer_growths += 1;                                       // the same pass again with buffers sized from the measured counts
+    } else if (any_fused && !orig.no_fuse) {
+        next.no_fuse = true;
+    } else if (any_mfma && !orig.force_exact) {
+        next.force_exact = true;
+        c->sstats.exact_pass_queries += (int64_t)again.size();
+    } else if (kprime >= n_total) {
+        return ORR_OK;
+    } else {
+        kprime = std::min<int64_t>(n_total, kprime * 4);
+    }
+    if (depth >= 40) return fail(ORR_EDEVICE, "orr_cluster_search_batch: escalation did not terminate");
+    return cluster_search_ids(c, next, again, false, kprime, n_total, out_rows, out_scores, out_counts, depth + 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int orr_cluster_create(const int32_t *devices, int32_t n_shards, int32_t dim, int64_t capacity_rows_per_shard, orr_cluster **out)
+{
+    if (!devices || !out || n_shards < 1 || n_shards > 64 || dim < 0 || capacity_rows_per_shard < 0)
+        return fail(ORR_EINVAL, "orr_cluster_create: bad argument");
+    *out = nullptr;
+    orr_cluster *c = new (std::nothrow) orr_cluster();
+    if (!c) return fail(ORR_ENOMEM, "out of host memory");
+    c->dim = dim;
+    for (int32_t i = 0; i < n_shards; ++i) {
+        orr_config cfg{(int32_t)sizeof(orr_config), devices[i], dim, 0, capacity_rows_per_shard, 0};
+        orr_index *sh = nullptr;
+        const int r = orr_index_create(&cfg, &sh);
+        if (r != ORR_OK) { const std::string keep = g_last_error; orr_cluster_destroy(c); g_last_error = keep; return r; }
+        c->shards.push_back(sh);
+    }
+    *out = c;
+    return ORR_OK;
+}
+
+void orr_cluster_destroy(orr_cluster *c)
+{
+    if (!c) return;
+    for (orr_index *sh : c->shards) orr_index_destroy(sh);
+    delete c;
+}
+
+int32_t orr_cluster_shards(const orr_cluster *c) { return c ? (int32_t)c->shards.size() : 0; }
+
+orr_index *orr_cluster_shard(orr_cluster *c, int32_t i)
+{
+    if (!c || i < 0 || i >= (int32_t)c->shards.size()) { (void)fail(ORR_EINVAL, "orr_cluster_shard: no shard %d", i); return nullptr; }
+    return c->shards[(size_t)i];
+}
+
+int64_t orr_cluster_rows(const orr_cluster *c)
+{
+    int64_t n = 0;
+    if (c) for (const orr_index *sh : c->shards) n += sh->n_rows;
+    return n;
+}
+
+int orr_cluster_seal(orr_cluster *c)
+{
+    if (!c) return fail(ORR_EINVAL, "orr_cluster_seal: null cluster");
+    std::lock_guard<std::mutex> lock(c->mu);
+    ORR_TRY(for_each_shard((int32_t)c->shards.size(), [&](int32_t g) { return orr_index_seal(c->shards[(size_t)g]); }));
+    int64_t base = 0, dead = 0;
+    const orr_index *prev = nullptr;
+    for (orr_index *sh : c->shards) {
+        // the global candidate order must be shard 0's rows, then shard 1's, ...: nothing in a shard may be newer than a row in front of it
+        if (prev && !prev->h_created.empty() && !sh->h_created.empty() && sh->h_created.front() > prev->h_created.back())
+            return fail(ORR_EINVAL, "orr_cluster_seal: a shard holds a row newer than one of the shard in front of it; "
+                                    "partition the rows by CreatedAtUtc, newest first");
+        ORR_TRY(orr_index_set_row_base(sh, base));
+        ORR_TRY(orr_index_set_option(sh, "dead_rows_before", dead));
+        base += sh->n_rows;
+        dead += (int64_t)sh->dead.size();
+        if (sh->n_rows > 0) prev = sh;
+    }
+    c->sealed = true;
+    return ORR_OK;
+}
+
+int orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, const float *q_host, const uint8_t *terms_utf8,
+                             const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+                             int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_counts)
+{
+    if (!c) return fail(ORR_EINVAL, "orr_cluster_search_batch: null cluster");
+    BatchArgs a{B, dim, q_host, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, topk};
+    ORR_TRY(check_batch(c->shards[0], a, "orr_cluster_search_batch"));
+    if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_cluster_search_batch: output buffers are required");
+    if (dim > 0 && is_device_pointer(q_host)) return fail(ORR_EINVAL, "orr_cluster_search_batch: the query vectors must be in host memory (every shard's device reads them)");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->sealed) return fail(ORR_ESTATE, "orr_cluster_search_batch: the cluster is not sealed");
+    const int32_t take = std::max<int32_t>(1, topk);
+    int64_t n_total = 0;
+    for (orr_index *sh : c->shards) n_total += participating_rows(sh, candidate_limit);
+    // k' per shard as orr_search_batch picks it for one shard: any shard may hold the whole top-k
+    int64_t kprime = std::min<int64_t>(std::max<int64_t>(1, n_total), std::max<int64_t>((int64_t)take + 22, 32));
+    if (kprime > orr::kSelWidth && take + 8 <= orr::kSelWidth) kprime = orr::kSelWidth;
+    c->sstats.searches += 1;
+    c->sstats.queries += B;
+    for (int64_t i = 0; i < (int64_t)B * take; ++i) { out_rows[i] = -1; out_scores[i] = 0.0; }
+    std::vector<int32_t> all((size_t)B);
+    std::iota(all.begin(), all.end(), 0);
+    return cluster_search_ids(c, a, all, true, kprime, n_total, out_rows, out_scores, out_counts, 0);
+}
+
+int orr_cluster_search_stats(orr_cluster *c, orr_search_stats *out, int32_t reset)
+{
+    if (!c) return fail(ORR_EINVAL, "orr_cluster_search_stats: null cluster");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (out) *out = c->sstats;
+    if (reset) c->sstats = orr_search_stats{};
+    return ORR_OK;
 }
 
 }  // extern "C"

@@ -228,6 +228,85 @@ class RecallIndex:
                                        "algo_bytes": float(arr[i].algo_bytes)} for i in range(min(n, 32))}
 
 
+class _BorrowedIndex(RecallIndex):
+    """A shard owned by a RecallCluster: usable like a RecallIndex, never destroyed through this object."""
+
+    def __init__(self, handle, dim: int, owner):
+        self._h = handle
+        self.dim = dim
+        self.row_base = 0
+        self._owner = owner                  # keeps the cluster alive
+
+    def close(self) -> None:
+        self._h = None
+
+
+class RecallCluster:
+    """orr_cluster: several shards (one per entry of `devices`) behind one handle in this process; searches answer as
+    one index over all the rows would.  shard(i) is a borrowed RecallIndex to append to (rows of shard i newer than or
+    as new as those of shard i + 1; pass explicit row_ids)."""
+
+    def __init__(self, devices: Sequence[int], dim: int, capacity_rows_per_shard: int = 0):
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        N.check(N.hip.orr_cluster_create(_ptr(devs), int(devs.shape[0]), dim, int(capacity_rows_per_shard), C.byref(h)))
+        self._h = h
+        self.dim = dim
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            N.hip.orr_cluster_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_shards(self) -> int:
+        return int(N.hip.orr_cluster_shards(self._h))
+
+    @property
+    def rows(self) -> int:
+        return int(N.hip.orr_cluster_rows(self._h))
+
+    def shard(self, i: int) -> RecallIndex:
+        p = N.hip.orr_cluster_shard(self._h, int(i))
+        if not p:
+            N.check(N.ORR_EINVAL)
+        return _BorrowedIndex(C.c_void_p(p), self.dim, self)
+
+    def seal(self) -> None:
+        N.check(N.hip.orr_cluster_seal(self._h))
+
+    def search(self, qvecs, queries_terms, now_ticks: int, topk: int, candidate_limit: int = 300):
+        """orr_cluster_search_batch; qvecs in host memory (numpy) or None."""
+        B = len(queries_terms)
+        if qvecs is None:
+            dim, q = 0, None
+        else:
+            q = np.ascontiguousarray(qvecs, dtype=np.float32).reshape(B, -1)
+            dim = int(q.shape[1])
+            q = q if dim > 0 else None
+        pool, toff, qoff = pack_terms(queries_terms)
+        k = max(1, int(topk))
+        rows = np.full((B, k), -1, dtype=np.int64)
+        scores = np.zeros((B, k), dtype=np.float64)
+        counts = np.zeros(B, dtype=np.int32)
+        N.check(N.hip.orr_cluster_search_batch(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks, int(topk),
+                                               int(candidate_limit), _ptr(rows), _ptr(scores), _ptr(counts)))
+        return rows, scores, counts
+
+    def search_stats(self, reset: bool = False) -> dict:
+        st = N.OrrSearchStats()
+        N.check(N.hip.orr_cluster_search_stats(self._h, C.byref(st), 1 if reset else 0))
+        d = {n: int(getattr(st, n)) for n, _ in N.OrrSearchStats._fields_ if n != "reserved"}
+        d["survivors_per_query"] = d["survivors_total"] / d["survivor_samples"] if d["survivor_samples"] else None
+        return d
+
+
 def merge_candidates(all_records: np.ndarray, index_dim: int, qvecs, queries_terms, now_ticks: int, topk: int):
     """orr_merge_candidates over [n_shards, B, kprime+1] records (host).  Returns
     (rows, scores, counts, uncertified)."""

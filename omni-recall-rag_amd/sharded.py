@@ -79,14 +79,19 @@ class ShardedRecallSearch:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit, out=, mode=) -> records [B,kprime+1]
+        # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit, out=, mode=, topk=) -> records [B,kprime+1]
         self._shard_search = shard_search or self._index_shard_search
         self._pinned = {}                      # name -> pinned host staging tensor (device runs only)
+        self._told_topk = 0
         self.collectives = 0                   # data-path collectives issued so far (diagnostic)
         self.escalations = 0                   # batches repeated with the exact pass or a larger k'
 
-    def _index_shard_search(self, q, terms, now, kprime, limit, out=None, mode=0):
-        # mode 0: the library picks the pass; 2: the exact pass (escalation after a failed certificate)
+    def _index_shard_search(self, q, terms, now, kprime, limit, out=None, mode=0, topk=0):
+        # mode 0: the library picks the pass; 2: the exact pass (escalation after a failed certificate).
+        # topk: the caller's k, so that the two-stage floor comes from the k-th best of the sample, not the k'-th
+        if topk != self._told_topk:
+            self.index.set_option("shard_topk", max(0, int(topk)))
+            self._told_topk = topk
         if mode:
             self.index.set_option("shard_pass", mode)
         try:
@@ -218,7 +223,7 @@ class ShardedRecallSearch:
         while True:
             rec_bytes = B * (kprime + 1) * CAND_DTYPE.itemsize
             mine = torch.empty(rec_bytes, dtype=torch.uint8, device=self.device)
-            self._shard_search(q_all, terms_all, now_ticks, kprime, candidate_limit, out=mine, mode=mode)
+            self._shard_search(q_all, terms_all, now_ticks, kprime, candidate_limit, out=mine, mode=mode, topk=max(1, int(topk)))
             if W > 1:
                 allrec = torch.empty(W * rec_bytes, dtype=torch.uint8, device=self.device)
                 dist.all_gather_into_tensor(allrec, mine, group=self.group)

@@ -28,7 +28,7 @@ def oracle_shard_search(P, orc, c, lo, hi):
     """Returns shard_search(q, terms, now, kprime, limit, out=...) over rows [lo, hi)."""
     import torch
 
-    def search(q_all, terms_all, now, kprime, limit, out=None, mode=0):
+    def search(q_all, terms_all, now, kprime, limit, out=None, mode=0, topk=0):
         B = len(terms_all)
         n_part = max(0, min(max(1, limit) - lo, hi - lo))
         rec = np.zeros((B, kprime + 1), dtype=P.CAND_DTYPE)
