@@ -58,7 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
     ap.add_argument("--no-legs", action="store_true", help="headline only: skip the C2 leg (one GPU) / the C4 legs (several)")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-steps-in-flight measurement of the C2 leg")
-    ap.add_argument("--clustered-leg", action="store_true", help="add a leg on a clustered corpus (64 centroids + 0.1 noise)")
+    ap.add_argument("--no-robustness-legs", action="store_true",
+                    help="skip the two 1M-row legs on unfriendly data: a clustered corpus (64 centroids + 0.1 noise: thousands of "
+                         "survivors per query) and a keyword-heavy one (2^18 Zipf-distributed tokens of mixed length, substring terms)")
     ap.add_argument("--no-terms", action="store_true", help="headline without keyword terms (cosine + recency only)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="orr_index_set_option on every shard before the run (e.g. two_stage=0)")
@@ -437,17 +439,21 @@ def main():
             legs_out["C2_1M_rows_1_query"] = run_leg(leg, args, env, idx2, None, syn, overlap=not args.no_overlap_leg)
             idx2.close()
             del idx2
-        if args.clustered_leg:
-            cl = importlib.import_module(graft.PKG_NAME + ".synthetic_clustered")
-            t0 = time.perf_counter()
-            idxc = build_shard(P, cl, torch, 0, 1_000_000, dim, 1_000_000, dev, args.set_option)
-            setup_s["clustered_corpus"] = time.perf_counter() - t0
-            for bq in (1, 256):
-                leg = Leg("clustered", "clustered corpus (64 centroids + 0.1 noise): " + workload_label(1_000_000, dim, bq, k, True, 1),
-                          1_000_000, 1_000_000, bq)
-                legs_out[f"clustered_1M_rows_{bq}_queries"] = run_leg(leg, args, env, idxc, None, cl)
-            idxc.close()
-            del idxc
+        if not args.no_legs and not args.no_robustness_legs:
+            for tag, modname, what in (("clustered", "synthetic_clustered", "clustered corpus (64 centroids + 0.1 noise)"),
+                                       ("keyword_heavy", "synthetic_zipf", "keyword-heavy corpus (2^18 Zipf tokens of 3..24 bytes, substring terms)")):
+                gen = importlib.import_module(graft.PKG_NAME + "." + modname)
+                t0 = time.perf_counter()
+                idxc = build_shard(P, gen, torch, 0, 1_000_000, dim, 1_000_000, dev, args.set_option)
+                setup_s[tag + "_corpus"] = time.perf_counter() - t0
+                for bq in (1, 256):
+                    leg = Leg(tag, what + ": " + workload_label(1_000_000, dim, bq, k, True, 1), 1_000_000, 1_000_000, bq)
+                    legs_out[f"{tag}_1M_rows_{bq}_queries"] = run_leg(leg, args, env, idxc, None, gen)
+                if tag == "clustered":       # without keyword steps in the scores the screen keeps thousands of pairs per query
+                    leg = Leg(tag, what + ": " + workload_label(1_000_000, dim, 256, k, False, 1), 1_000_000, 1_000_000, 256, terms=False)
+                    legs_out["clustered_1M_rows_256_queries_cosine_only"] = run_leg(leg, args, env, idxc, None, gen)
+                idxc.close()
+                del idxc
         torch.cuda.empty_cache()
         # ---- headline: C3 (configs[2])
         t0 = time.perf_counter()

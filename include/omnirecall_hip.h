@@ -109,7 +109,10 @@ typedef struct orr_search_stats {
     int64_t survivor_samples;    /* queries counted in survivors_total                                        */
     int64_t survivors_max;       /* largest count of one query                                                */
     int64_t survivor_capacity;   /* buffer entries per query the index uses now                               */
-    int64_t reserved[5];
+    int64_t vocab_tokens;        /* distinct whitespace-free tokens of the shard's contents (the keyword index)  */
+    int64_t kw_hits_total;       /* (distinct query term, vocabulary token containing it) pairs, summed over passes */
+    int64_t kw_passes;           /* passes that had query terms                                                */
+    int64_t reserved[2];
 } orr_search_stats;
 
 int         orr_abi_version(void);
@@ -237,6 +240,9 @@ int64_t orr_index_live_rows(const orr_index *idx);
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "dead_rows_before"  deleted rows in the shards in front of this one (default 0), see above.
+ *   "kw_hits_cap"    entries of the keyword chain's hit list, one per (distinct query term, vocabulary token containing it)
+ *                    (default 16M = 384 MB at most).  A batch that needs more grows the list to the measured count and
+ *                    repeats its pass; the option exists to pre-size it (or, in tests, to force that path).
  *   "shard_pass"     0/1/2 (default 0): which pass orr_search_shard runs -- 0 the library's choice, 1 the unfused
  *                    batched pass, 2 the reference-arithmetic pass over every row.  The caller of
  *                    orr_merge_candidates sets 2 for the repeat of a batch some query of which could not be certified.

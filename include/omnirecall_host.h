@@ -122,10 +122,13 @@ void orrh_free(void *p);
  * The reference serves one SearchAsync per request thread (scoped service, Program.cs:59);
  * the GPU's batched paths need tens to hundreds of queries per call.  The batcher
  * coalesces concurrent single-query calls into one orr_search_batch: a worker thread takes
- * the first waiting request, keeps collecting compatible ones (same dim, now_ticks and
+ * the first waiting request, keeps collecting compatible ones (same dim and
  * candidate_limit) until max_batch are there or max_wait_us have passed, runs the batch
- * with the largest topk among them (a smaller topk is a prefix of a larger one) and wakes
- * the callers.  index is the orr_index* the requests are answered from (not owned). */
+ * with the largest topk among them (a smaller topk is a prefix of a larger one) at ONE
+ * clock -- the latest now_ticks of its requests: callers pass DateTime.UtcNow.Ticks, which
+ * never repeats, and a batch's requests are at most max_wait_us apart (rule F3: one frozen
+ * clock per search) -- and wakes the callers.  index is the orr_index* the requests are
+ * answered from (not owned). */
 typedef struct orrh_batcher orrh_batcher;
 orrh_batcher *orrh_batcher_create(void *index, int32_t max_batch, int32_t max_wait_us);
 void          orrh_batcher_destroy(orrh_batcher *b);
@@ -134,6 +137,11 @@ void          orrh_batcher_destroy(orrh_batcher *b);
 int orrh_batcher_search(orrh_batcher *b, int32_t dim, const float *q, const uint8_t *terms_utf8,
                         const uint32_t *term_off, int32_t n_terms, int64_t now_ticks, int32_t topk,
                         int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_count);
+/* The same; *out_batch_now (may be NULL) receives the clock the request's batch was answered at. */
+int orrh_batcher_search_at(orrh_batcher *b, int32_t dim, const float *q, const uint8_t *terms_utf8,
+                           const uint32_t *term_off, int32_t n_terms, int64_t now_ticks, int32_t topk,
+                           int64_t candidate_limit, int64_t *out_rows, double *out_scores, int32_t *out_count,
+                           int64_t *out_batch_now);
 /* Batches dispatched and requests served so far (for tests and metrics). */
 void orrh_batcher_stats(orrh_batcher *b, int64_t *batches, int64_t *requests, int32_t *largest_batch);
 

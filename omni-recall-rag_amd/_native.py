@@ -44,7 +44,7 @@ class OrrKernelStat(C.Structure):
 class OrrSearchStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("searches", "queries", "passes", "requeried", "overflowed_queries", "buffer_growths",
                                          "exact_pass_queries", "survivors_total", "survivor_samples", "survivors_max",
-                                         "survivor_capacity")] + [("reserved", C.c_int64 * 5)]
+                                         "survivor_capacity", "vocab_tokens", "kw_hits_total", "kw_passes")] + [("reserved", C.c_int64 * 2)]
 
 
 def _load(path: str) -> C.CDLL:
@@ -168,6 +168,8 @@ host.orrh_batcher_destroy.restype = None
 host.orrh_batcher_destroy.argtypes = [_vp]
 host.orrh_batcher_search.restype = C.c_int
 host.orrh_batcher_search.argtypes = [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]
+host.orrh_batcher_search_at.restype = C.c_int
+host.orrh_batcher_search_at.argtypes = [_vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp]
 host.orrh_batcher_stats.restype = None
 host.orrh_batcher_stats.argtypes = [_vp, _vp, _vp, _vp]
 host.orrh_batcher_create.restype = _vp
@@ -193,7 +195,7 @@ EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_te
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_store_import_cosmos_json", "orrh_store_export_cosmos_json", "orrh_service_create", "orrh_service_destroy",
                          "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
-                         "orrh_batcher_search", "orrh_batcher_stats"]
+                         "orrh_batcher_search", "orrh_batcher_search_at", "orrh_batcher_stats"]
 
 
 def check(status: int) -> None:

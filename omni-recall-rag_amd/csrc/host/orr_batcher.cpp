@@ -16,6 +16,7 @@
 
 #include "../../../include/omnirecall_hip.h"
 #include "../../../include/omnirecall_host.h"
+#include "orr_store.h"
 
 namespace {
 
@@ -33,6 +34,8 @@ struct Request {
     int32_t *out_count;
     int status = 1;            // 1 = pending
     bool done = false;
+    int64_t batch_now = 0;     // the clock the batch was answered at (see run_batch)
+    std::string error;         // the library's message when status != ORR_OK (it was set on the worker's thread)
 };
 
 }  // namespace
@@ -53,9 +56,13 @@ struct orrh_batcher {
 
 namespace {
 
+// Requests that may share a batch.  NOT their clocks: the C# shim passes DateTime.UtcNow.Ticks per request (100 ns
+// resolution), so no two production requests ever carry the same now_ticks; the batch is answered at ONE clock, the
+// latest of its requests' (the reference reads the clock per chunk, RecallSearchService.cs:117; one frozen clock per
+// search is this build's documented rule F3, and requests of one batch are at most max_wait_us apart).
 bool compatible(const Request *a, const Request *b)
 {
-    return a->dim == b->dim && a->now_ticks == b->now_ticks && a->candidate_limit == b->candidate_limit;
+    return a->dim == b->dim && a->candidate_limit == b->candidate_limit;
 }
 
 void run_batch(orr_index *index, std::vector<Request *> &batch)
@@ -63,7 +70,8 @@ void run_batch(orr_index *index, std::vector<Request *> &batch)
     const int32_t B = (int32_t)batch.size();
     const int32_t dim = batch[0]->dim;
     int32_t topk = 1;
-    for (auto r : batch) topk = std::max(topk, std::max(1, r->topk));
+    int64_t now = batch[0]->now_ticks;
+    for (auto r : batch) { topk = std::max(topk, std::max(1, r->topk)); now = std::max(now, r->now_ticks); }
     std::vector<float> q((size_t)B * (size_t)std::max(dim, 0) + 1);
     std::vector<uint8_t> terms;
     std::vector<uint32_t> term_off{0}, qoff{0};
@@ -82,11 +90,14 @@ void run_batch(orr_index *index, std::vector<Request *> &batch)
     std::vector<double> scores((size_t)B * topk, 0.0);
     std::vector<int32_t> counts((size_t)B, 0);
     const int st = orr_search_batch(index, B, dim, dim > 0 ? q.data() : nullptr, terms.data(), term_off.data(), qoff.data(),
-                                    batch[0]->now_ticks, topk, batch[0]->candidate_limit, rows.data(), scores.data(),
+                                    now, topk, batch[0]->candidate_limit, rows.data(), scores.data(),
                                     counts.data());
+    const std::string err = st == ORR_OK ? std::string() : std::string(orr_last_error());
     for (int32_t i = 0; i < B; ++i) {
         Request *r = batch[i];
         r->status = st;
+        r->batch_now = now;
+        r->error = err;
         if (st == ORR_OK) {
             const int32_t k = std::max(1, r->topk);
             const int32_t n = std::min(k, counts[i]);          // a smaller topk is a prefix of the batch's
@@ -161,19 +172,29 @@ void orrh_batcher_destroy(orrh_batcher *b)
     delete b;
 }
 
+int orrh_batcher_search_at(orrh_batcher *b, int32_t dim, const float *q, const uint8_t *terms_utf8, const uint32_t *term_off,
+                           int32_t n_terms, int64_t now_ticks, int32_t topk, int64_t candidate_limit, int64_t *out_rows,
+                           double *out_scores, int32_t *out_count, int64_t *out_batch_now)
+{
+    if (!b || !out_rows || !out_scores || dim < 0 || n_terms < 0 || (dim > 0 && !q) || (n_terms > 0 && (!terms_utf8 || !term_off)))
+        return orrh_detail::fail(ORR_EINVAL, "orrh_batcher_search: bad argument");
+    Request r{dim, q, terms_utf8, term_off, n_terms, now_ticks, topk, candidate_limit, out_rows, out_scores, out_count};
+    std::unique_lock<std::mutex> lk(b->mu);
+    if (b->stop) return orrh_detail::fail(ORR_ESTATE, "orrh_batcher_search: the batcher is shutting down");
+    b->queue.push_back(&r);
+    b->cv_work.notify_one();
+    b->cv_done.wait(lk, [&r] { return r.done; });
+    if (out_batch_now) *out_batch_now = r.batch_now;
+    if (r.status != ORR_OK) return orrh_detail::fail(r.status, r.error);      // the text crosses from the worker's thread to the caller's
+    return r.status;
+}
+
 int orrh_batcher_search(orrh_batcher *b, int32_t dim, const float *q, const uint8_t *terms_utf8, const uint32_t *term_off,
                         int32_t n_terms, int64_t now_ticks, int32_t topk, int64_t candidate_limit, int64_t *out_rows,
                         double *out_scores, int32_t *out_count)
 {
-    if (!b || !out_rows || !out_scores || dim < 0 || n_terms < 0 || (dim > 0 && !q) || (n_terms > 0 && (!terms_utf8 || !term_off)))
-        return ORR_EINVAL;
-    Request r{dim, q, terms_utf8, term_off, n_terms, now_ticks, topk, candidate_limit, out_rows, out_scores, out_count};
-    std::unique_lock<std::mutex> lk(b->mu);
-    if (b->stop) return ORR_ESTATE;
-    b->queue.push_back(&r);
-    b->cv_work.notify_one();
-    b->cv_done.wait(lk, [&r] { return r.done; });
-    return r.status;
+    return orrh_batcher_search_at(b, dim, q, terms_utf8, term_off, n_terms, now_ticks, topk, candidate_limit, out_rows, out_scores,
+                                  out_count, nullptr);
 }
 
 void orrh_batcher_stats(orrh_batcher *b, int64_t *batches, int64_t *requests, int32_t *largest_batch)

@@ -165,6 +165,7 @@ struct orr_index {
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
     std::vector<double> h_norm_a;      // exact query norms of the batch in flight (run_shard -> host finish)
     std::vector<uint32_t> h_survivors; // two-stage pass: (query,row) pairs the screen kept, per query of the batch in flight (else empty)
+    uint32_t kw_hits_cap = 16u << 20;  // (term, token) matches the hit list of the keyword chain holds; grows to the measured count when a batch exceeds it
     uint32_t survivor_cap = 8192;      // entries per query of the survivors' buffers; grows when a query overflows it (clustered corpora)
     uint32_t pass_cap = 8192;          // what the pass in flight uses: survivor_cap, halved until a batch's buffers stay below 2 GiB
     orr_search_stats sstats{};         // orr_index_search_stats
@@ -192,7 +193,7 @@ struct orr_index {
     DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
     size_t bitmaps_clean = 0;          // leading bytes of ws_bitmaps known to be zero (cleared again behind every search)
     const void *bitmaps_clean_of = nullptr;
-    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm, pin_cnt;
+    PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm, pin_cnt, pin_kwcnt;
     hipEvent_t ev_q = nullptr;
 
     // profiling
@@ -559,7 +560,7 @@ void orr_index_destroy(orr_index *idx)
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
     idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
-    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release(); idx->pin_norm.release(); idx->pin_cnt.release();
+    idx->pin_meta.release(); idx->pin_q.release(); idx->pin_qc.release(); idx->pin_cand.release(); idx->pin_norm.release(); idx->pin_cnt.release(); idx->pin_kwcnt.release();
     if (idx->ev_q) (void)hipEventDestroy(idx->ev_q);
     if (idx->stream) (void)hipStreamDestroy(idx->stream);
     delete idx;
@@ -1072,6 +1073,11 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
         idx->dead_before = value;
         return ORR_OK;
     }
+    if (strcmp(name, "kw_hits_cap") == 0) {
+        if (value < 1 || value > (int64_t)0x7FFFFFFF) return fail(ORR_EINVAL, "orr_index_set_option: kw_hits_cap must be in 1 .. 2^31-1");
+        idx->kw_hits_cap = (uint32_t)value;
+        return ORR_OK;
+    }
     if (strcmp(name, "shard_topk") == 0) {
         if (value < 0 || value > 1 << 30) return fail(ORR_EINVAL, "orr_index_set_option: shard_topk must be >= 0");
         idx->opt_shard_topk = (int)value;
@@ -1303,8 +1309,10 @@ HostTiming g_ht;
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
 // the query vectors in host memory (valid until the next call).  Caller holds the lock.
-int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
-              const orr_candidate **recs_host)
+constexpr int kRetryPass = 1;          // run_shard_once: a workspace was too small and has been enlarged; the same pass again
+
+int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
+                   const orr_candidate **recs_host)
 {
     g_ht.start();
     ORR_TRY(bind_device(idx));
@@ -1487,7 +1495,7 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         const int64_t V = idx->n_tokens;
         const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
         const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
-        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, 16u << 20);
+        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, idx->kw_hits_cap);
         ORR_TRY(ensure_vlong(idx));
         const int64_t VL = idx->n_vlong;
         ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
@@ -1535,6 +1543,8 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
                                                 idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k));
             }
         }
+        ORR_TRY(idx->pin_kwcnt.reserve(sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpyAsync(idx->pin_kwcnt.p, idx->ws_counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, k));   // hits of this pass: statistics
         HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
         kw.bitmaps = idx->ws_bitmaps.as<uint32_t>();
         kw.words_per_term = words;
@@ -1968,6 +1978,10 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
         idx->bitmaps_clean = std::max(bm_bytes, bm_clean_before);
     }
     if (dev_norms) memcpy(idx->h_norm_a.data(), idx->pin_norm.p, sizeof(double) * (size_t)B);
+    if (n_terms_total > 0) {
+        idx->sstats.kw_hits_total += (int64_t)(*idx->pin_kwcnt.as<unsigned long long>() >> 32);
+        idx->sstats.kw_passes += 1;
+    }
     if (a.used_two_stage) {
         idx->h_survivors.assign(idx->pin_cnt.as<uint32_t>(), idx->pin_cnt.as<uint32_t>() + B);
         uint64_t sum = 0;
@@ -1981,13 +1995,31 @@ int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_reco
     if (kw_overflow_possible) {
         unsigned long long cnt = 0;
         HIP_TRY(hipMemcpy(&cnt, idx->ws_counter.p, sizeof(cnt), hipMemcpyDeviceToHost));
-        if ((uint32_t)(cnt >> 32) > kw_max_hits)
-            return fail(ORR_ENOMEM, "keyword terms matched %u vocabulary tokens, more than the %u-entry hit list holds",
-                        (uint32_t)(cnt >> 32), kw_max_hits);
+        const uint32_t hits = (uint32_t)(cnt >> 32);
+        if (hits > kw_max_hits) {
+            // the distinct terms of this batch match more vocabulary tokens than the hit list holds (short terms against a
+            // large vocabulary): the bitmaps are incomplete, so this pass's records are discarded; the list grows to the
+            // measured count and the pass runs again (the index keeps the larger list)
+            if ((uint64_t)hits * sizeof(orr::KwHit) > ((uint64_t)8 << 30))
+                return fail(ORR_ENOMEM, "keyword terms matched %u vocabulary tokens: a hit list of that size is refused (8 GiB)", hits);
+            idx->kw_hits_cap = hits + hits / 4 + 1024u;
+            return kRetryPass;
+        }
     }
     if (recs_host && direct_host) *recs_host = d_cand;
     else if (recs_host && host_records) *recs_host = idx->pin_cand.as<orr_candidate>();
     return ORR_OK;
+}
+
+int run_shard(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
+              const orr_candidate **recs_host)
+{
+    for (int attempt = 0;; ++attempt) {
+        const int r = run_shard_once(idx, a, kprime, host_records, q_host, recs_host);
+        if (r != kRetryPass) return r;
+        idx->sstats.passes += 1;
+        if (attempt >= 3) return fail(ORR_EDEVICE, "the keyword hit list kept overflowing");
+    }
 }
 
 // Host finish for one query over records from any number of shards.
@@ -2273,6 +2305,7 @@ int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset)
     if (!idx) return fail(ORR_EINVAL, "orr_index_search_stats: null index");
     std::lock_guard<std::mutex> lock(idx->mu);
     idx->sstats.survivor_capacity = idx->survivor_cap;
+    idx->sstats.vocab_tokens = idx->n_tokens;
     if (out) *out = idx->sstats;
     if (reset) { const int64_t cap = idx->sstats.survivor_capacity; idx->sstats = orr_search_stats{}; idx->sstats.survivor_capacity = cap; }
     return ORR_OK;

@@ -342,18 +342,22 @@ class MicroBatcher:
         if not self._h:
             raise ValueError("orrh_batcher_create failed")
 
-    def search(self, qvec, terms: Sequence[bytes], now_ticks: int, topk: int, candidate_limit: int = 300):
+    def search(self, qvec, terms: Sequence[bytes], now_ticks: int, topk: int, candidate_limit: int = 300, with_clock: bool = False):
+        """One request.  with_clock: also return the clock its batch was answered at (the latest now_ticks of the batch)."""
         q = None if qvec is None else np.ascontiguousarray(qvec, dtype=np.float32).reshape(-1)
         dim = 0 if q is None else int(q.shape[0])
         pool, toff, _ = pack_terms([terms])
         k = max(1, int(topk))
         rows = np.full(k, -1, dtype=np.int64)
         scores = np.zeros(k, dtype=np.float64)
-        cnt = C.c_int32(0)
-        st = N.host.orrh_batcher_search(self._h, dim, _ptr(q) if dim else None, _ptr(pool), _ptr(toff), len(terms),
-                                        now_ticks, int(topk), int(candidate_limit), _ptr(rows), _ptr(scores),
-                                        C.cast(C.byref(cnt), C.c_void_p))
-        N.check(st)
+        cnt, clock = C.c_int32(0), C.c_int64(0)
+        st = N.host.orrh_batcher_search_at(self._h, dim, _ptr(q) if dim else None, _ptr(pool), _ptr(toff), len(terms),
+                                           now_ticks, int(topk), int(candidate_limit), _ptr(rows), _ptr(scores),
+                                           C.cast(C.byref(cnt), C.c_void_p), C.cast(C.byref(clock), C.c_void_p))
+        if st != N.ORR_OK:
+            raise N.OrrError(st, (N.host.orrh_last_error() or b"").decode("utf-8", "replace"))
+        if with_clock:
+            return rows[:cnt.value], scores[:cnt.value], int(clock.value)
         return rows[:cnt.value], scores[:cnt.value]
 
     def stats(self):

@@ -45,6 +45,44 @@ def test_concurrent_requests_are_batched_and_exact():
     idx.close()
 
 
+def test_requests_with_their_own_clocks_still_share_batches():
+    """The C# shim passes DateTime.UtcNow.Ticks per request: no two requests carry the same now_ticks.  They must still
+    be coalesced; a batch is answered at its latest clock, which the caller can ask for -- the result then equals the
+    oracle's at that clock."""
+    P = pkg()
+    rng = np.random.default_rng(19)
+    n, dim = 3000, 64
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    n_req = 64
+    qs = rng.standard_normal((n_req, dim)).astype(np.float32)
+    texts = [["alpha kubernetes", "the helm", "GAMMA delta zzz", "net ab"][i % 4] for i in range(n_req)]
+    nows = [NOW + 1_000 * i + int(rng.integers(0, 999)) for i in range(n_req)]          # all different, 100 us apart
+    batcher = P.MicroBatcher(idx, max_batch=32, max_wait_us=20000)
+    results = [None] * n_req
+    barrier = threading.Barrier(n_req)
+
+    def work(i):
+        barrier.wait()
+        results[i] = batcher.search(qs[i], P.text.query_terms(texts[i]), nows[i], 5, candidate_limit=n, with_clock=True)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_req)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    st = batcher.stats()
+    assert st["requests"] == n_req and st["largest_batch"] > 1 and st["batches"] < n_req, st
+    for i in range(n_req):
+        rows, scores, clock = results[i]
+        assert clock in nows and clock >= nows[i], (i, clock)
+        orow, osc, _ = corpus.search(qs[i], texts[i], clock, 5, candidate_limit=n)
+        assert list(rows) == list(orow) and np.array_equal(scores, osc), i
+    batcher.close()
+    idx.close()
+
+
 def test_concurrent_unbatched_searches_are_serialised_safely():
     P = pkg()
     rng = np.random.default_rng(18)

@@ -780,3 +780,34 @@ def test_empty_and_degenerate_inputs():
         orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 4, candidate_limit=300)
         assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc)
     idx.close()
+
+
+def test_keyword_hit_list_overflow_grows_the_list_and_repeats_the_pass():
+    """Short terms against a large vocabulary match more (term, token) pairs than the hit list holds: round 1 failed the
+    whole batch with ORR_ENOMEM.  Now the list grows to the measured count and the pass runs again; forced here with a
+    16-entry list."""
+    P = pkg()
+    rng = np.random.default_rng(321)
+    n, dim = 3000, 32
+    syll = ["ka", "re", "mi", "to", "ne", "su", "lo", "vi", "da", "po", "er", "in"]
+    contents = [" ".join("".join(rng.choice(syll, size=int(rng.integers(2, 5)))) for _ in range(int(rng.integers(3, 12)))) for _ in range(n)]
+    c = {"emb": [rng.standard_normal(dim).astype(np.float32) for _ in range(n)],
+         "created": (NOW - rng.integers(0, 200 * DAY, n)).astype(np.int64), "contents": contents, "dim": dim}
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    idx.set_option("kw_hits_cap", 16)
+    qs = rng.standard_normal((6, dim)).astype(np.float32)
+    texts = ["e in", "ka re mi", "er", "to ne su lo", "zzz", "in er ka"]            # one- and two-letter terms: substrings of hundreds of tokens
+    terms = [P.text.query_terms(t) for t in texts]
+    idx.reset_search_stats()
+    rows, scores, counts = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    ss = idx.search_stats()
+    assert ss["passes"] >= 2, ss                                                   # the overflowing pass + its repeat
+    for b in range(6):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n)
+        assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), b
+    # the larger list stays: the same batch again needs no repeat
+    idx.reset_search_stats()
+    rows2, scores2, _ = idx.search(qs, terms, NOW, 10, candidate_limit=n)
+    assert idx.search_stats()["passes"] == 1 and np.array_equal(rows2, rows) and np.array_equal(scores2, scores)
+    idx.close()

@@ -290,3 +290,72 @@ def test_evidence_guard_and_prompt_score_text_consume_the_same_scores():
     for raw, text in ((0.30000000000000004, "0.3000"), (0.9999999999999999, "1.0000"), (0.1, "0.1000"),
                       (0.12345, "0.1234"), (0.12355, "0.1236"), (0.0, "0.0000"), (12.5, "12.5000")):
         assert T.format_score_f4(T.round4(raw)) == text, raw
+
+
+def _guard_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chat_guard_cases.json")) as f:
+        return json.load(f)
+
+
+def test_evidence_guard_on_the_references_own_fixtures():
+    """The three guard cases the reference's tests hold (ChatOrchestrationServiceTests.cs:97-181), as data."""
+    T = pkg().text
+    for case in _guard_cases()["cases"]:
+        got = T.has_sufficient_evidence(case["citation_scores"], case["minimum_citation_count"], case["minimum_strong_citation_score"])
+        assert got is case["sufficient"], case["source"]
+
+
+@pytest.mark.gpu
+def test_chat_evidence_guard_and_prompt_text_fed_by_the_hip_path():
+    """SURVEY §8(f) #4 as a parity test: citations produced by the HIP scorer (orrh_service_search_json: the
+    /api/recall/search body with Math.Round(score, 4)) go through HasSufficientEvidence and the `score={c.Score:F4}`
+    prompt text (ChatOrchestrationService.cs:58-65,85) at every threshold pair the reference's tests and defaults use;
+    the oracle's rounded scores for the same store go through an independent restatement of both.  The decisions and
+    the prompt lines must be identical, for queries whose best score lies on either side of each threshold."""
+    S = _svc()
+    T = pkg().text
+    rng = np.random.default_rng(4242)
+    dim, n_docs = 16, 40
+    store = S.InMemoryIngestionStore()
+    words = ["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "azure", "cosmos", "vector", "search", "the", "of"]
+    emb, created, contents = [], [], []
+    for d in range(n_docs):
+        t = NOW - int(rng.integers(0, 200)) * 864000000000 - d
+        store.UpsertDocument(S.CosmosDocumentRecord("doc-%02d" % d, "file-%02d.md" % d, t))
+        chunks = []
+        for i in range(3):
+            e = None if (d + i) % 7 == 0 else (rng.standard_normal(dim) * (0.05 if d % 5 == 0 else 1.0)).astype(np.float32)
+            text = " ".join(rng.choice(words, size=int(rng.integers(3, 9))))
+            chunks.append(S.CosmosChunkRecord("doc-%02d:%04d" % (d, i), "doc-%02d" % d, i, text, None if e is None else e.tolist(), t))
+            emb.append(e); created.append(t); contents.append(text)
+        store.UpsertChunks(chunks)
+    corpus = orc.OracleCorpus(emb, np.asarray(created, dtype=np.int64), contents)
+    thresholds = _guard_cases()["thresholds_used_by_the_reference"]
+    outcomes = set()
+    queries = [("kubernetes helm", rng.standard_normal(dim)), ("zzz unknown", rng.standard_normal(dim) * 1e-3), ("azure", None),
+               ("the of", rng.standard_normal(dim)), ("vector search cosmos", np.asarray(emb[4]) * 3.0), ("nothing here", None)]
+    for text, vec in queries:
+        v = [] if vec is None else np.asarray(vec, dtype=np.float32)
+        sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(v), candidate_limit=300, now_ticks=NOW)
+        for topk in (1, 2, 5):
+            body = sut.Search(text, topk)
+            got_scores = [c["score"] for c in body["citations"]]
+            orow, osc, ornd = corpus.search(v, text, NOW, topk, candidate_limit=300)
+            assert got_scores == list(ornd), (text, topk)                        # the 4-decimal scores the consumer sees
+            for th in thresholds:
+                cnt, thr = th["minimum_citation_count"], th["minimum_strong_citation_score"]
+                want = len(ornd) >= max(1, cnt) and any(x >= max(0.0, thr) for x in ornd)        # :58-65 restated
+                got = T.has_sufficient_evidence(got_scores, cnt, thr)
+                assert got is want, (text, topk, th)
+                outcomes.add((cnt, thr, got))
+            for c, r in zip(body["citations"], ornd):                            # :85  score={c.Score:F4}
+                line = "[1] file=%s chunk=%d score=%s" % (c["fileName"], c["chunkIndex"], T.format_score_f4(c["score"]))
+                assert line.endswith("score=%.4f" % r), (line, r)
+        sut.close()
+    # both outcomes occurred at every threshold pair: the test saw scores on either side
+    for th in thresholds:
+        key = (th["minimum_citation_count"], th["minimum_strong_citation_score"])
+        assert (key[0], key[1], True) in outcomes and (key[0], key[1], False) in outcomes, (key, sorted(outcomes))
+    store.close()
