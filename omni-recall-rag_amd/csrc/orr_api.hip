@@ -958,8 +958,6 @@ static int ensure_shadow(orr_index *idx)
 static int ensure_i8_shadow(orr_index *idx)
 {
     if (idx->is_view || idx->i8_ready || idx->i8_failed || !idx->sealed || idx->n_rows <= 0 || idx->dim <= 0 || idx->dim % 128 != 0) return ORR_OK;
-    static const bool off = [] { const char *e = getenv("ORR_I8_SHADOW"); return e && atoi(e) == 0; }();
-    if (off) { idx->i8_failed = true; return ORR_OK; }
     const size_t bytes = orr::i8_tiled_bytes(idx->n_rows, idx->dim) + 28 * (size_t)idx->n_rows;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + bytes / 8 + ((size_t)8 << 30)) {   // keep 8 GiB for workspaces
@@ -1272,8 +1270,6 @@ bool is_device_pointer(const void *p)
 // with the default sample of 200k rows against 14 ms for the screen itself; four times the sample, a quarter of both).
 static int32_t sample_segments(int32_t n_seg_all, int64_t n, int32_t k, bool small_batch, int boost)
 {
-    static const int forced = [] { const char *e = getenv("ORR_TS_SAMPLE_SEGS"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return std::min<int32_t>(forced, n_seg_all);
     const int64_t rows = (int64_t)std::max<int32_t>(1, k) * n / 2000 * std::max(1, boost);
     const int64_t segs = (rows + orr::kSelSegRows - 1) / orr::kSelSegRows;
     const int64_t most = std::min<int64_t>(64 * (int64_t)std::max(1, boost), std::max<int64_t>(n_seg_all / 8, 4));   // never more than an eighth of the rows
@@ -1303,7 +1299,7 @@ struct HostTiming {
         for (double &x : acc) x = 0;
     }
 };
-HostTiming g_ht;
+thread_local HostTiming g_ht;          // per searching thread: lanes (views) and cluster workers each time their own calls
 
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
@@ -1338,7 +1334,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     const size_t rec_bytes = sizeof(orr_candidate) * rec_count;
     // Batched candidate pass on the matrix cores (K2) + exact re-score (K6) from this batch size
     // up; below it the HBM-bound exact kernel is as fast and needs no second pass.
-    static const int mfma_min_batch = [] { const char *e = getenv("ORR_MFMA_MIN_BATCH"); return e ? atoi(e) : 5; }();
+    constexpr int mfma_min_batch = 5;
     // 1..8 queries over a large shard with a shadow in place: the streaming form of the two-stage pass
     // (stream over a sampled prefix -> floor, stream over all rows -> survivors, exact re-score)
     bool ts_stream = false, ts_i8 = false;
@@ -1351,8 +1347,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         ts_stream = ts_i8 || idx->shadow_ready;
         // 5..8 queries on the int8 shadow: the screening GEMM with one live query tile is HBM-bound as well and
         // reads the rows once, the stream would need two launches (1M x 3072: 8 queries 1.39 -> 0.97 ms)
-        static const int i8_stream_max = [] { const char *e = getenv("ORR_I8_STREAM_MAX"); return e ? atoi(e) : orr::kMaxI8ScreenQ; }();
-        if (ts_i8 && B > i8_stream_max) { ts_i8 = false; ts_stream = false; }
+        if (ts_i8 && B > orr::kMaxI8ScreenQ) { ts_i8 = false; ts_stream = false; }
     }
     const bool use_mfma = use_cos && !a.force_exact && (B >= mfma_min_batch || ts_stream) && idx->dim % 64 == 0 && kprime <= orr::kSelWidth;
     const bool approx_pass = use_mfma;                   // records carry no dot yet: filled in exactly on the device
@@ -1381,7 +1376,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     idx->h_norm_a.assign((size_t)B, 0.0);
     if (use_cos) {
         const size_t qbytes = sizeof(float) * (size_t)B * a.dim;
-        static const int dev_norm_min = [] { const char *e = getenv("ORR_DEV_NORMS_MIN_BATCH"); return e ? atoi(e) : 16; }();
+        constexpr int dev_norm_min = 16;
         if (is_device_pointer(a.q) && kprime <= orr::kSelWidth && B >= dev_norm_min && !a.norms_host) {
             // (a handful of queries: the download and the host's pass cost less than the kernel's 3072-step chains)
             d_q = a.q;
@@ -1567,7 +1562,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     bool prefix_i8 = false;            // the sampled prefix went through the int8 screening GEMM: its keys are lower bounds
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
-        if (!ts_stream && (B <= 64 || getenv("ORR_GEMM_KIND"))) {
+        if (!ts_stream && B <= 64) {
             ORR_TRY(idx->ws_dotf.reserve(sizeof(float) * (size_t)B * (size_t)n));
             d_dotf = idx->ws_dotf.as<float>();
         }
@@ -1575,7 +1570,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         // against 2.35 ms streaming, 32 queries 2.28 against 3.07, 64 queries 2.4 against 6.3); ORR_TS_MIN_BATCH moves that
         const bool ts_eligible = idx->opt_two_stage != 0 && !a.no_fuse && (n + orr::kSelSegRows - 1) / orr::kSelSegRows >= 48 &&
                                  std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
-        static const int ts_min_batch = [] { const char *e = getenv("ORR_TS_MIN_BATCH"); return e ? atoi(e) : 5; }();
+        constexpr int ts_min_batch = 5;
         if (ts_stream) {
             // 1..8 queries: HBM-bound, so no GEMM tile: the streaming screen (K2i on the int8 shadow, else K2g on the
             // bf16 one) runs over the sample for the floor and then over all rows
@@ -1600,12 +1595,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 HIP_TRY(orr::launch_gemv_mfma(d_q + (size_t)b0 * a.dim, nq, idx->d_emb, n, idx->dim, d_dotf + (size_t)b0 * n, n, s));
             }
         } else {
-            static const bool f32_gemm = [] { const char *e = getenv("ORR_GEMM_KIND"); return e && strcmp(e, "f32") == 0; }();
-            if (f32_gemm) {
-                Timed t(idx, "gemm_dot_f32", 4.0 * (double)n * idx->dim * ((B + 127) / 128) + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)n);
-                HIP_TRY(orr::launch_gemm_dot_f32(d_q, B, idx->d_emb, n, idx->dim, d_dotf, n, s));
-            } else {
-                // split bf16: queries split once; with enough rows the GEMM over everything behind a
+            {   // split bf16: queries split once; with enough rows the GEMM over everything behind a
                 // sampled prefix runs with the fused scoring epilogue (launched further down, once the
                 // floor keys exist) and only the prefix's dots go through HBM
                 ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
@@ -1619,9 +1609,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 d_dotf = idx->ws_dotf.as<float>();
                 // Where the int8 shadow exists the sampled prefix goes through the int8 screening GEMM as well (integer
                 // dots out; fuse_select turns them into LOWER bounds of the scores with the per-pair bound), which reads
-                // a quarter of the bytes of the split pass and runs at twice its MFMA rate.  ORR_I8_PREFIX=0: split pass.
-                static const bool i8_prefix_on = [] { const char *e = getenv("ORR_I8_PREFIX"); return !e || atoi(e) != 0; }();
-                if (two_stage && fused_sample_seg > 0 && idx->opt_two_stage == 1 && idx->dim % 128 == 0 && i8_prefix_on) {
+                // a quarter of the bytes of the split pass and runs at twice its MFMA rate.
+                if (two_stage && fused_sample_seg > 0 && idx->opt_two_stage == 1 && idx->dim % 128 == 0) {
                     ORR_TRY(ensure_i8_shadow(idx));
                     prefix_i8 = idx->i8_ready;
                 }

@@ -1,12 +1,12 @@
 // orr_gemm.hip -- batched candidate pass (K2) and exact re-score of the survivors (K6).
 //
-// K2: approximate dots S[b][r] = sum_k Q[b][k] * E[r][k] for a whole batch on the matrix
-// cores with the f32-input MFMA v_mfma_f32_32x32x2_f32 (D products and D additions in fp32,
-// each charged one full ulp: |S - reference dot| <= (2D+2) * 2^-23 * sum|q_k e_k|; the cores'
-// internal rounding is not documented, see orr_api.hip).  It only has to be good enough to
-// pick k' >= k candidates per query; K6 then recomputes the survivors' dots in the
-// reference's own arithmetic (RecallSearchService.cs:77-82) and the host certifies the
-// result against the cut-off (orr_api.hip).
+// K2b / K2s: approximate dots S[b][r] = sum_k Q[b][k] * E[r][k] for a whole batch on the matrix cores -- three bf16
+// products of hi/lo splits (K2b, `gemm_dot_bf16x3`) or the f32-input MFMA in a streaming form for up to 32 queries per
+// launch (K2s, `gemv_mfma`); each comes with a bound on |S - reference dot| (orr_api.hip).  They only have to be good
+// enough to pick k' >= k candidates per query; K6 then recomputes the survivors' dots in the reference's own
+// arithmetic (RecallSearchService.cs:77-82) and the host certifies the result against the cut-off (orr_api.hip).
+// (The round-1 f32 MFMA GEMMs, 111 TFLOP/s at 256 queries, were superseded by the split-bf16 and int8 passes and
+// are gone from this file; profiles/r01_pmc_mfma_gemm_b256_v1.json keeps their measurement.)
 #include "orr_kernels.h"
 #include "orr_device.h"
 #include "orr_epilogue.h"
@@ -18,110 +18,9 @@ namespace orr {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// ---------------------------------------------------------------------------
-// K2  128 x 128 output tile per workgroup (queries x rows), BK = 64, 4 waves as 2 x 2,
-// each wave a 64 x 64 sub-tile = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).
-//
-// LDS image of an operand tile: [128 rows][2 halves][32] floats with a 68-float row
-// stride.  Half h of a row holds its k = h, h+2, h+4, ... (the 32x32x2 MFMA wants
-// A[i][k = lane>>5] and B[k = lane>>5][j] with i/j = lane & 31), so every lane reads its
-// operand values for 4 consecutive MFMAs with one ds_read_b128; the 272-byte stride puts
-// the 16 lanes of each ds_read_b128 group on 16 different 16-byte slots.
-// Global -> LDS goes through registers (the even/odd split needs it): every row piece is
-// 256 contiguous bytes, the next K-step's loads are in flight while this one is computed.
-// ---------------------------------------------------------------------------
-constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 64, kGemmLd = 68;
+// K depth of one step of the bf16x3 GEMM and the streaming MFMA kernels below
+constexpr int kGemmBK = 64;
 
-__device__ __forceinline__ void stage_write(float *tile, int r, int c4, const float4 &v)
-{
-    // row r, k = 4*c4 .. 4*c4+3  ->  evens to half 0, odds to half 1, at position k/2
-    float *row = tile + r * kGemmLd;
-    *reinterpret_cast<float2 *>(row + 2 * c4) = make_float2(v.x, v.z);
-    *reinterpret_cast<float2 *>(row + 32 + 2 * c4) = make_float2(v.y, v.w);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_dot_f32_kernel(const float *__restrict__ Q, int32_t B,
-                                                              const float *__restrict__ E, int64_t n_rows, int32_t D,
-                                                              float *__restrict__ S, int64_t s_stride)
-{
-    __shared__ __attribute__((aligned(16))) float lds_a[kGemmBM * kGemmLd];
-    __shared__ __attribute__((aligned(16))) float lds_b[kGemmBN * kGemmLd];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                       // wave's 64 x 64 sub-tile
-    const int64_t n0 = (int64_t)blockIdx.x * kGemmBN;
-    const int b0 = blockIdx.y * kGemmBM;
-
-    // staging assignment: 8 loads per operand per thread; load it covers rows it*16 + tid/16,
-    // 16-byte chunk tid%16 of the 256-byte row piece
-    const int ld_r = tid >> 4, ld_c = tid & 15;
-    float4 ra[8], rb[8];
-    auto load_stage = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            // rows past the end are clamped, not branched around (a branch per load makes hipcc wait
-            // vmcnt(0) between loads); what they contribute lands in outputs that are never stored
-            const int r = it * 16 + ld_r;
-            const int qr = (b0 + r < B) ? b0 + r : B - 1;
-            const int64_t er = (n0 + r < n_rows) ? n0 + r : n_rows - 1;
-            ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)qr * D + k0 + ld_c * 4);
-            const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + er * (int64_t)D + k0 + ld_c * 4));
-            rb[it] = make_float4(v.x, v.y, v.z, v.w);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const float *pa = lds_a + (wm * 64 + fr) * kGemmLd + fh * 32;
-    const float *pb = lds_b + (wn * 64 + fr) * kGemmLd + fh * 32;
-
-    load_stage(0);
-    for (int k0 = 0; k0 < D; k0 += kGemmBK) {
-        __syncthreads();                                            // previous step's fragment reads are done
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            stage_write(lds_a, it * 16 + ld_r, ld_c, ra[it]);
-            stage_write(lds_b, it * 16 + ld_r, ld_c, rb[it]);
-        }
-        if (k0 + kGemmBK < D) load_stage(k0 + kGemmBK);             // in flight during the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);                          // keep the loads ABOVE the MFMA block
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {                               // 4 k-pairs per group
-            const float4 a0 = *reinterpret_cast<const float4 *>(pa + 4 * g);
-            const float4 a1 = *reinterpret_cast<const float4 *>(pa + 32 * kGemmLd + 4 * g);
-            const float4 c0 = *reinterpret_cast<const float4 *>(pb + 4 * g);
-            const float4 c1 = *reinterpret_cast<const float4 *>(pb + 32 * kGemmLd + 4 * g);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {c0.x, c0.y, c0.z, c0.w}, bv1[4] = {c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
-            }
-        }
-    }
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = n0 + wn * 64 + j * 32 + fr;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------
 // K2b  split-bf16 candidate pass: every fp32 operand x is split on the fly into
@@ -521,11 +420,9 @@ hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float
     if (B <= 0 || n_rows <= row_first) return hipSuccess;
     if (D % kGemmBK != 0) return hipErrorInvalidValue;
     const __bf16 *q_hi = static_cast<const __bf16 *>(q_split_ws), *q_lo = q_hi + (size_t)B * D;
-    static const int variant = [] { const char *e = getenv("ORR_BF16_TILE"); return e ? atoi(e) : 128; }();
     const FusedEpilogue none{};
     if (epi && products == 1) return launch_bf16x3_variant<2, true, true, 1>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, *epi, s);
     if (epi) return launch_bf16x3_variant<2, true, true, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, *epi, s);
-    if (variant == 256) return launch_bf16x3_variant<4, false, false, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
     return launch_bf16x3_variant<2, true, false, 3>(q_hi, q_lo, B, E, row_first, n_rows, D, S, s_stride, none, s);
 }
 
@@ -801,13 +698,10 @@ hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q
 {
     if (B <= 0) return hipSuccess;
     if (D % 64 != 0) return hipErrorInvalidValue;
-    static const bool via_lds = [] { const char *e = getenv("ORR_RESCORE_LDS"); return e && atoi(e) != 0; }();
-    static const int quad_max = [] { const char *e = getenv("ORR_RESCORE_QUAD_MAX_BATCH"); return e ? atoi(e) : 64; }();
-    if (D % 256 == 0 && B <= quad_max && !via_lds)
+    // four lanes per survivor while the kernel's latency is on the critical path of the call (small batches), one row per
+    // lane beyond (measured crossover: 64 queries)
+    if (D % 256 == 0 && B <= 64)
         hipLaunchKernelGGL(rescore_buffer_exact_quad_kernel, dim3((unsigned)B, cap / 16), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
-                           now_ticks, cnt, cap, buf, buf_dot);
-    else if (via_lds)
-        hipLaunchKernelGGL(rescore_buffer_exact_kernel<true>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
                            now_ticks, cnt, cap, buf, buf_dot);
     else
         hipLaunchKernelGGL(rescore_buffer_exact_kernel<false>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
@@ -842,122 +736,6 @@ hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint
     return hipGetLastError();
 }
 
-// K2 v2: same tile and LDS image, but the image is DOUBLE-BUFFERED (139 KiB: one workgroup
-// per CU, one wave per SIMD) and the staging of K-step t+1 (ds_write of registers loaded one
-// step earlier) and the global loads of K-step t+2 are issued from INSIDE the MFMA block of
-// K-step t, with one barrier per K-step.  Measured (B=256, 1M rows): 16.0 ms against 14.2 ms
-// for v1 once v1's per-load branches were removed -- with one wave per SIMD the LDS-read
-// latency at the head of every MFMA group is exposed, v1's second wave covers it.  Kept as
-// ORR_GEMM_VARIANT=2 for comparison; v1 is the default.
-__global__ __launch_bounds__(256, 1) void gemm_dot_f32_db_kernel(const float *__restrict__ Q, int32_t B,
-                                                                 const float *__restrict__ E, int64_t n_rows, int32_t D,
-                                                                 float *__restrict__ S, int64_t s_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][A 128x68 | B 128x68]
-    constexpr int kTile = kGemmBM * kGemmLd;                        // floats per operand tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int64_t n0 = (int64_t)blockIdx.x * kGemmBN;
-    const int b0 = blockIdx.y * kGemmBM;
-    const int ld_r = tid >> 4, ld_c = tid & 15;
-    float4 ra[8], rb[8];
-    auto load_stage = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            // rows past the end are clamped, not branched around (a branch per load makes hipcc wait
-            // vmcnt(0) between loads); what they contribute lands in outputs that are never stored
-            const int r = it * 16 + ld_r;
-            const int qr = (b0 + r < B) ? b0 + r : B - 1;
-            const int64_t er = (n0 + r < n_rows) ? n0 + r : n_rows - 1;
-            ra[it] = *reinterpret_cast<const float4 *>(Q + (int64_t)qr * D + k0 + ld_c * 4);
-            const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(E + er * (int64_t)D + k0 + ld_c * 4));
-            rb[it] = make_float4(v.x, v.y, v.z, v.w);
-        }
-    };
-    auto store_stage = [&](float *buf) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            stage_write(buf, it * 16 + ld_r, ld_c, ra[it]);
-            stage_write(buf + kTile, it * 16 + ld_r, ld_c, rb[it]);
-        }
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const int fr = lane & 31, fh = lane >> 5;
-    const int a_off = (wm * 64 + fr) * kGemmLd + fh * 32;
-    const int b_off = kTile + (wn * 64 + fr) * kGemmLd + fh * 32;
-
-    const int n_steps = D / kGemmBK;
-    load_stage(0);
-    store_stage(lds);
-    if (n_steps > 1) load_stage(kGemmBK);
-    for (int t = 0; t < n_steps; ++t) {
-        const float *cur = lds + (t & 1) * 2 * kTile;
-        float *nxt = lds + ((t + 1) & 1) * 2 * kTile;
-        __syncthreads();          // image t complete; everyone is done reading image t-1 (= nxt)
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(cur + a_off + 4 * g);
-            const float4 a1 = *reinterpret_cast<const float4 *>(cur + a_off + 32 * kGemmLd + 4 * g);
-            const float4 c0 = *reinterpret_cast<const float4 *>(cur + b_off + 4 * g);
-            const float4 c1 = *reinterpret_cast<const float4 *>(cur + b_off + 32 * kGemmLd + 4 * g);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {c0.x, c0.y, c0.z, c0.w}, bv1[4] = {c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
-            }
-            if (g == 1) {         // behind 32 MFMAs: stage image t+1 from the registers loaded a step ago
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < n_steps) store_stage(nxt);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (g == 3) {         // and put K-step t+2 in flight
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 2 < n_steps) load_stage((t + 2) * kGemmBK);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t col = n0 + wn * 64 + j * 32 + fr;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = b0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = acc[i][j][e];
-            }
-        }
-}
-
-hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
-                               int64_t s_stride, hipStream_t s)
-{
-    if (B <= 0 || n_rows <= 0) return hipSuccess;
-    if (D % kGemmBK != 0) return hipErrorInvalidValue;
-    dim3 grid((unsigned)((n_rows + kGemmBN - 1) / kGemmBN), (unsigned)((B + kGemmBM - 1) / kGemmBM));
-    static const int variant = [] { const char *e = getenv("ORR_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant == 1) {
-        hipLaunchKernelGGL(gemm_dot_f32_kernel, grid, dim3(256), 0, s, Q, B, E, n_rows, D, S, s_stride);
-        return hipGetLastError();
-    }
-    constexpr size_t lds_bytes = sizeof(float) * 4 * kGemmBM * kGemmLd;          // 139,264 B
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_f32_db_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(gemm_dot_f32_db_kernel, grid, dim3(256), lds_bytes, s, Q, B, E, n_rows, D, S, s_stride);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------
 // K2s  up to 32 queries per launch, HBM-bound: the streaming structure of
@@ -1192,9 +970,7 @@ hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32
 {
     if (B <= 0 || D <= 0) return hipSuccess;
     if (kprime <= 64 && D % 64 == 0 && (reinterpret_cast<uintptr_t>(E) & 15) == 0) {
-        static const bool via_lds = [] { const char *e = getenv("ORR_RESCORE_LDS"); return e && atoi(e) != 0; }();
-        if (via_lds) hipLaunchKernelGGL(rescore_exact_kernel<true>, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
-        else hipLaunchKernelGGL(rescore_exact_kernel<false>, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
+        hipLaunchKernelGGL(rescore_exact_kernel<false>, dim3((unsigned)B), dim3(64), 0, s, E, D, Q, B, kprime, row_base, recs);
     } else {
         const int64_t threads = (int64_t)B * kprime;
         hipLaunchKernelGGL(rescore_exact_generic, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, D, Q, B, kprime,

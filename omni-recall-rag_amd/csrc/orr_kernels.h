@@ -143,10 +143,6 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
                                unsigned long long *tau_out, const uint32_t *fused_cnt, uint32_t fused_cap,
                                const double *two_stage_L, orr_candidate *out, hipStream_t s);
 
-// K2: S[b][r] ~= sum_k Q[b][k] * E[r][k] on the matrix cores (f32-input MFMA, fmaf chain in k
-// order).  D must be a multiple of 64.  S is [B][s_stride] fp32.
-hipError_t launch_gemm_dot_f32(const float *Q, int32_t B, const float *E, int64_t n_rows, int32_t D, float *S,
-                               int64_t s_stride, hipStream_t s);
 // Fused epilogue of the batched candidate pass: score, compare with the query's floor key,
 // append survivors to the query's buffer (cap entries; cnt keeps counting past it).
 struct FusedEpilogue {

@@ -198,19 +198,10 @@ hipError_t launch_dot_exact(const float *E, int64_t n_rows, int32_t D, const flo
     }
     const int64_t n_groups = (n_rows + 63) / 64;
     int64_t blocks = (n_groups + 3) / 4;
-    static const int variant = [] { const char *e = getenv("ORR_DOT_VARIANT"); return e ? atoi(e) : 2; }();
-    static const int wg_per_cu = [] { const char *e = getenv("ORR_DOT_WG_PER_CU"); return e ? atoi(e) : 16; }();
-    if (blocks > 256 * (int64_t)wg_per_cu) blocks = 256 * (int64_t)wg_per_cu;   // grid-stride beyond that
+    if (blocks > 256 * 16) blocks = 256 * 16;                               // 16 workgroups per CU, grid-stride beyond that (measured best of 2..16)
     dim3 grid((unsigned)blocks), block(256);
-#define ORR_LAUNCH_DOT(NQ_, SELF_)                                                                                    \
-    do {                                                                                                              \
-        if (variant == 0)                                                                                             \
-            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, false, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride); \
-        else if (variant == 1)                                                                                        \
-            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true, false>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);  \
-        else                                                                                                          \
-            hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true, true>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride);   \
-    } while (0)
+    // (register prefetch of the next piece + non-temporal loads: the fastest of the three forms measured in round 1)
+#define ORR_LAUNCH_DOT(NQ_, SELF_) hipLaunchKernelGGL((dot_exact_tiled<NQ_, SELF_, true, true>), grid, block, 0, s, E, n_rows, D, Q, out, out_stride)
     if (self_norm) {
         ORR_LAUNCH_DOT(1, true);
     } else {

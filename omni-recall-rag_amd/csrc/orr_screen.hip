@@ -62,15 +62,6 @@ constexpr int kScEpiQueue = 7;
 constexpr int kScLds = (kScNA + kScNB) * kScImage + kScEpiBytes;       // 160 KiB
 static_assert(kScLds <= 160 * 1024, "the rings and the epilogue's region must fit a CU's LDS");
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-template <int AUX>
-__device__ __forceinline__ void glds16(const void *g, unsigned char *l)
-{
-    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, AUX);
-}
-
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef int i32x16v __attribute__((ext_vector_type(16)));
 
@@ -735,14 +726,12 @@ __global__ __launch_bounds__(256) void i8_tile_queries_kernel(const int8_t *__re
 }
 
 // Workgroups to start for the screening GEMM: one per CU (it holds all of a CU's LDS), each walking its share of
-// the output tiles; a multiple of 8 keeps an id's XCD fixed along the walk.  ORR_SCREEN_PERSIST=0: one per tile.
+// the output tiles; a multiple of 8 keeps an id's XCD fixed along the walk.
 // k_tiles = K-tiles per output tile (D / 64 for int8, D / 32 for bf16).
 static int64_t screen_grid(int64_t tiles, int32_t k_tiles)
 {
     if (k_tiles < kScNB) return tiles;        // the requests of a tile reach kScNB K-tiles ahead: never past the next output tile
     static const int64_t per_launch = [] {
-        const char *e = getenv("ORR_SCREEN_PERSIST");
-        if (e && atoi(e) == 0) return (int64_t)0;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return (int64_t)0;
         return (int64_t)(cus / 8 * 8);
@@ -770,7 +759,7 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
+    constexpr int flags = 1;                                               // rows of single-query-tile launches are requested non-temporal
     // ORR_SCREEN_STAMPS=file (diagnostic): every launch appends its workgroups' per-tile phase stamps to the file
     static const char *stamp_path = getenv("ORR_SCREEN_STAMPS");
     static unsigned long long *d_stamps = nullptr;
@@ -931,7 +920,7 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const __bf16 *q_hi = static_cast<const __bf16 *>(q_tiled), *eh = static_cast<const __bf16 *>(e_shadow);
     const FusedEpilogue none{};
-    static const int flags = [] { const char *e = getenv("ORR_SCREEN_NT"); return e ? atoi(e) : 1; }();
+    constexpr int flags = 1;                                               // rows of single-query-tile launches are requested non-temporal
 #define ORR_LAUNCH_LIVE(F, L, E) do { \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, false, L>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
