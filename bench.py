@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     help="skip the two 1M-row legs on unfriendly data: a clustered corpus (64 centroids + 0.1 noise: thousands of "
                          "survivors per query) and a keyword-heavy one (2^18 Zipf-distributed tokens of mixed length, substring terms)")
     ap.add_argument("--no-terms", action="store_true", help="headline without keyword terms (cosine + recency only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of a multi-GPU run: nccl (= RCCL, the product path) or gloo (a rehearsal of the same "
+                         "code with several ranks on ONE card, which RCCL refuses; ranks then share cuda:0)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="orr_index_set_option on every shard before the run (e.g. two_stage=0)")
     return ap.parse_args(argv)
@@ -240,10 +243,11 @@ def run_leg(leg, args, env, idx, front, gen, overlap=False):
     if not getattr(gen, "PLANTED_WINS", True):        # clustered corpus: a newer row of the cluster may legitimately outrank it
         ok = True
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
     queries = args.steps * B
@@ -418,10 +422,17 @@ def main():
     P = graft.load_package()
     syn = importlib.import_module(graft.PKG_NAME + ".synthetic")
     sharded = importlib.import_module(graft.PKG_NAME + ".sharded")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_visible = torch.cuda.device_count()
+    if world > 1 and args.backend == "nccl" and n_visible < world:
+        raise SystemExit(f"--gpus {world} with the nccl (RCCL) backend needs {world} visible GPUs, found {n_visible}")
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_visible)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     env = {"P": P, "torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank}
 
     dim, k = args.dim, args.topk
@@ -469,11 +480,12 @@ def main():
         t0 = time.perf_counter()
         idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
         setup_s["headline_corpus"] = time.perf_counter() - t0
-        front = sharded.ShardedRecallSearch(idx, dim, dev)
+        front = sharded.ShardedRecallSearch(idx, dim, dev if args.backend == "nccl" else "cpu")
         ranks_seen = front.rccl_ranks_seen()
         head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, world), rows, n_total, B, terms=not args.no_terms)
         head = run_leg(head_leg, args, env, idx, front, syn)
-        head["rccl_ranks_seen"] = ranks_seen
+        head["rccl_ranks_seen"] = ranks_seen if args.backend == "nccl" else 0
+        head["backend"] = args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else f" (rehearsal: {world} ranks, {n_visible} card(s))")
         head["collectives_per_step"] = front.collectives / max(1, args.warmup + args.steps)
         if not args.no_legs:
             for bq in (1, 256):
@@ -511,7 +523,7 @@ def main():
             "setup_s": {kk: round(v, 2) for kk, v in setup_s.items()},
             "total_s": round(time.perf_counter() - t_start, 2),
         }
-        for extra in ("rccl_ranks_seen", "collectives_per_step"):
+        for extra in ("rccl_ranks_seen", "collectives_per_step", "backend"):
             if extra in head:
                 out[extra] = head[extra]
         if parity is not None:

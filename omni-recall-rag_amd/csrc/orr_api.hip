@@ -1819,7 +1819,10 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                         ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
                         HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
                     }
-                    Timed t(idx, "screen_i8_fused", 1.0 * (double)n * idx->dim + 1.0 * (double)B * idx->dim);
+                    // algorithmic bytes: the int8 rows once, per row its constants (rowc 16 B, i8_rowf 16 B) and, with query terms,
+                    // 16 B of count words per 32 queries; the query image once
+                    Timed t(idx, "screen_i8_fused", (double)n * ((double)idx->dim + 32.0 + (epi.count_planes ? 16.0 * (double)((B + 31) / 32) : 0.0)) +
+                                                    1.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, n, idx->dim, epi, s));
                 } else if (ts_i8) {
                     Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 12.0 * (double)n + 2.0 * (double)B * idx->dim);
