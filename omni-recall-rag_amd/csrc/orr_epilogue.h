@@ -139,14 +139,24 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
             // query past the batch was staged with a floor of +inf.
             unsigned long long wave_any = 0ull;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float4 qf = qf_of(i, e);
+            for (int e0 = 0; e0 < 16; e0 += 4) {
+                // four queries' constants requested together: left to itself the compiler issues each LDS read right in front
+                // of its use (registers are short), one exposed LDS trip per element
+                float4 qf8[4];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
-                    const float a = (float)acc[i][j][e];
-                    const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
-                    wave_any |= __builtin_amdgcn_ballot_w64(!(upper < qf.y));      // NaN bounds (float accumulators that overflowed) are kept
+                for (int e = 0; e < 4; ++e) qf8[e] = qf_of(i, e0 + e);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e1 = 0; e1 < 4; ++e1) {
+                    const int e = e0 + e1;
+                    const float4 qf = qf8[e1];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
+                        const float a = (float)acc[i][j][e];
+                        const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
+                        wave_any |= __builtin_amdgcn_ballot_w64(!(upper < qf.y));      // NaN bounds (float accumulators that overflowed) are kept
+                    }
                 }
             }
             if (wave_any == 0ull) {
