@@ -99,7 +99,7 @@ def host_probe():
             if "gfx950" in a and "Compute Unit" in a:
                 m_cu = re.search(r"Compute Unit:\s+(\d+)", a)
                 m_clk = re.search(r"Max Clock Freq\. \(MHz\):\s+(\d+)", a)
-                m_name = re.search(r"Marketing Name:\s+(.+)", a)
+                m_name = re.search(r"Marketing Name:[ \t]+(\S.*)", a)
                 out["gpu"] = {"name": m_name.group(1).strip() if m_name else None,
                               "compute_units": int(m_cu.group(1)) if m_cu else None,
                               "max_clock_mhz": int(m_clk.group(1)) if m_clk else None}
