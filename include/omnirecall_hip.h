@@ -268,7 +268,9 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
 int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, float *out);
 
 /* ---- measurement ---------------------------------------------------------*/
-int orr_index_set_profiling(orr_index *idx, int32_t enabled);     /* also resets the counters */
+/* enabled: 0 off; 1 an event pair around every kernel; 2 only around the one launch per search that streams every row
+ * (each pair costs a few microseconds of stream time, which a one-query search notices).  Also resets the counters. */
+int orr_index_set_profiling(orr_index *idx, int32_t enabled);
 int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap);  /* returns count */
 
 int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset);  /* out may be NULL (reset only) */

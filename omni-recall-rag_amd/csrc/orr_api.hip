@@ -197,7 +197,7 @@ struct orr_index {
     hipEvent_t ev_q = nullptr;
 
     // profiling
-    bool profiling = false;
+    int profiling = 0;                     // 0 off, 1 every kernel, 2 only the pass over all rows (the kernel a roofline is quoted on)
     std::vector<KernelStat> stats;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
@@ -229,12 +229,19 @@ hipEvent_t take_event(orr_index *idx)
 
 // Brackets one launch with events on the index's stream when profiling is on.
 struct Timed {
+    // the one launch per search that streams every row (an event pair costs a few microseconds of stream time each, which a
+    // one-query search notices: level 2 times just this kernel)
+    static bool over_all_rows(const char *name)
+    {
+        return (strncmp(name, "screen_", 7) == 0 && !strstr(name, "prefix")) || strncmp(name, "gemm_dot", 8) == 0 ||
+               strcmp(name, "dot_exact") == 0 || strcmp(name, "gemv_mfma") == 0;
+    }
     orr_index *idx;
     PendingEvent pe;
     bool on;
     hipStream_t st;
     Timed(orr_index *i, const char *name, double algo_bytes, hipStream_t stream = nullptr)
-        : idx(i), on(i->profiling), st(stream ? stream : i->stream)
+        : idx(i), on(i->profiling == 1 || (i->profiling == 2 && over_all_rows(name))), st(stream ? stream : i->stream)
     {
         if (!on) return;
         pe.stat = stat_slot(idx, name);
@@ -1174,7 +1181,7 @@ int orr_index_set_profiling(orr_index *idx, int32_t enabled)
 {
     if (!idx) return fail(ORR_EINVAL, "null index");
     std::lock_guard<std::mutex> lock(idx->mu);
-    idx->profiling = enabled != 0;
+    idx->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     idx->stats.clear();
     return ORR_OK;
 }
@@ -1355,7 +1362,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     a.used_fused = false;
     a.used_two_stage = false;
     idx->h_survivors.clear();
-    const bool direct_host = host_records && !approx_pass && rec_bytes <= (256u << 10);
+    bool direct_host = host_records && !approx_pass && rec_bytes <= (256u << 10);
     orr_candidate *d_cand = nullptr;
     if (direct_host) {
         ORR_TRY(idx->pin_cand.reserve(rec_bytes));
@@ -1715,7 +1722,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             const int32_t lists_total = fused_sample_seg + buf_lists;
             ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)lists_total * orr::kSelWidth));
             ORR_TRY(idx->ws_tau.reserve(sizeof(unsigned long long) * (size_t)B));
-            ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * (size_t)B));
+            ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * 3 * (size_t)B));      // [survivors][sampled prefix][workgroups done]
             ORR_TRY(idx->ws_fbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * kCap));
             d_tau = idx->ws_tau.as<unsigned long long>();
             if (!ts_gemv) {
@@ -1740,7 +1747,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             epi.qf = idx->ws_fqf.as<float4>();
             epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw;
             epi.cnt = idx->ws_fcnt.as<uint32_t>(); epi.buf = idx->ws_fbuf.as<orr::SelEntry>(); epi.cap = kCap;
-            HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
+            HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * 3 * (size_t)B, s));
             if (two_stage) {
                 // ---- two-stage: floor from the k-th best split-pass score of the prefix; ONE plain-bf16
                 // product over ALL rows keeps every row that can still reach it; those are re-scored
@@ -1754,6 +1761,11 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                           : 0.7 * 1.01 * (0.0078125 * (1.0 + 0.001953125) + 1.02 * (double)idx->dim * 1.1920928955078125e-07) + 1e-12;
                 ORR_TRY(idx->ws_tsL.reserve(sizeof(double) * (size_t)B));
                 ORR_TRY(idx->ws_tskey.reserve(sizeof(unsigned long long) * (size_t)B));
+                // the floor comes out of the sampling selection's own launch
+                orr::FloorOut floor;
+                floor.floor_key = idx->ws_tskey.as<unsigned long long>();
+                floor.L = idx->ws_tsL.as<double>();
+                floor.eps3 = approx_eps; floor.eps1 = eps1;
                 if (ts_gemv) {
                     // the sample goes through the stream too: floor keys of 0 keep every sampled row, their
                     // approximate keys are sorted in lists of 64 and the k-th best one per query is the floor's base
@@ -1767,6 +1779,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     pre.tau = idx->ws_zero.as<unsigned long long>();
                     pre.buf = idx->ws_pbuf.as<orr::SelEntry>();
                     pre.cap = cap_p;
+                    pre.cnt = idx->ws_fcnt.as<uint32_t>() + B;         // its own counters: one memset for both launches
                     {
                         Timed t(idx, "screen_gemv_prefix", (ts_i8 ? 1.0 : 2.0) * (double)dotf_rows * idx->dim + 2.0 * (double)B * idx->dim);
                         if (ts_i8)
@@ -1781,15 +1794,12 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                         const int32_t lists_p = (int32_t)(cap_p / orr::kSelWidth);
                         ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
                         HIP_TRY(orr::launch_buffer_to_lists(pre.buf, pre.cnt, cap_p, B, 0, lists_p, idx->ws_psel.as<orr::SelEntry>(), s));
-                        HIP_TRY(orr::launch_select_final_sample(idx->ws_psel.as<orr::SelEntry>(), lists_p, lists_p, B, kth, d_tau, s));
+                        HIP_TRY(orr::launch_select_final_sample(idx->ws_psel.as<orr::SelEntry>(), lists_p, lists_p, B, kth, d_tau, s, floor));
                     }
-                    HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * (size_t)B, s));
                 } else {
                     Timed t(idx, "select_floor", 0.0);
-                    HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kth, d_tau, s));
+                    HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kth, d_tau, s, floor));
                 }
-                HIP_TRY(orr::launch_two_stage_floor(d_tau, B, approx_eps, eps1, idx->ws_tskey.as<unsigned long long>(),
-                                                    idx->ws_tsL.as<double>(), s));
                 // the screening GEMM runs on the int8 shadow where there is one (K2j), else on the bf16 shadow (K2c),
                 // else it converts the fp32 rows itself
                 bool gemm_i8 = false;
@@ -1841,32 +1851,46 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     Timed t(idx, "gemm_dot_bf16x1_fused", 4.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, n, idx->dim, nullptr, 0, &epi, 1, s));
                 }
-                {
-                    Timed t(idx, "rescore_buffer_exact", 0.0);
-                    ORR_TRY(idx->ws_fdot.reserve(sizeof(double) * (size_t)B * kCap));
-                    HIP_TRY(orr::launch_rescore_buffer_exact(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, kw,
-                                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf,
-                                                             idx->ws_fdot.as<double>(), s));
-                }
-                {
-                    Timed t(idx, "buffer_to_lists", 0.0);
-                    HIP_TRY(orr::launch_buffer_to_lists(epi.buf, epi.cnt, kCap, B, 0, buf_lists, idx->ws_sel.as<orr::SelEntry>(), s));
-                }
-                {
-                    Timed t(idx, "select_final", (double)B * (double)buf_lists * orr::kSelWidth * sizeof(orr::SelEntry));
-                    HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), buf_lists, B, kprime, n, idx->row_base,
-                                                     nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                                     0, 0.0, nullptr, epi.cnt, kCap, idx->ws_tsL.as<double>(), d_cand, s));
-                }
-                {   // the records' exact dots come out of the buffer: no second K6 pass
-                    Timed t(idx, "records_dot_from_buffer", 0.0);
-                    HIP_TRY(orr::launch_records_dot_from_buffer(epi.buf, idx->ws_fdot.as<double>(), epi.cnt, kCap, B, kprime, idx->row_base,
-                                                                d_cand, s));
-                    records_have_dots = true;
-                }
-                // the survivors' counts go back with the records: per-query escalation and orr_index_search_stats
+                ORR_TRY(idx->ws_fdot.reserve(sizeof(double) * (size_t)B * kCap));
                 ORR_TRY(idx->pin_cnt.reserve(sizeof(uint32_t) * (size_t)B));
-                HIP_TRY(hipMemcpyAsync(idx->pin_cnt.p, epi.cnt, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+                if (B <= 64 && idx->dim % 256 == 0) {
+                    // the tail in one launch; small record sets go straight into pinned host memory (they are final when written)
+                    if (host_records && !a.out_dev && rec_bytes <= (256u << 10)) {
+                        ORR_TRY(idx->pin_cand.reserve(rec_bytes));
+                        d_cand = idx->pin_cand.as<orr_candidate>();
+                        direct_host = true;
+                    }
+                    Timed t(idx, "finish_survivors", 0.0);
+                    HIP_TRY(orr::launch_finish_survivors(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                                         idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, idx->ws_fcnt.as<uint32_t>() + 2 * B,
+                                                         kCap, epi.buf, idx->ws_fdot.as<double>(), idx->ws_sel.as<orr::SelEntry>(), kprime, n,
+                                                         idx->row_base, idx->ws_tsL.as<double>(), d_cand, idx->pin_cnt.as<uint32_t>(), s));
+                } else {
+                    {
+                        Timed t(idx, "rescore_buffer_exact", 0.0);
+                        HIP_TRY(orr::launch_rescore_buffer_exact(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, kw,
+                                                                 idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf,
+                                                                 idx->ws_fdot.as<double>(), s));
+                    }
+                    {
+                        Timed t(idx, "buffer_to_lists", 0.0);
+                        HIP_TRY(orr::launch_buffer_to_lists(epi.buf, epi.cnt, kCap, B, 0, buf_lists, idx->ws_sel.as<orr::SelEntry>(), s));
+                    }
+                    {
+                        Timed t(idx, "select_final", (double)B * (double)buf_lists * orr::kSelWidth * sizeof(orr::SelEntry));
+                        HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), buf_lists, B, kprime, n, idx->row_base,
+                                                         nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                                         0, 0.0, nullptr, epi.cnt, kCap, idx->ws_tsL.as<double>(), d_cand, s));
+                    }
+                    {   // the records' exact dots come out of the buffer: no second K6 pass
+                        Timed t(idx, "records_dot_from_buffer", 0.0);
+                        HIP_TRY(orr::launch_records_dot_from_buffer(epi.buf, idx->ws_fdot.as<double>(), epi.cnt, kCap, B, kprime, idx->row_base,
+                                                                    d_cand, s));
+                    }
+                    // the survivors' counts go back with the records: per-query escalation and orr_index_search_stats
+                    HIP_TRY(hipMemcpyAsync(idx->pin_cnt.p, epi.cnt, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+                }
+                records_have_dots = true;
                 a.used_two_stage = true;
             } else {
             {

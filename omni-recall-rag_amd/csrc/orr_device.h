@@ -26,6 +26,26 @@ __device__ __forceinline__ double key_score(unsigned long long k)
     return __longlong_as_double((long long)u);
 }
 
+// Two-stage pass, floor: with s_k = the k-th best sampled score (key tau_k),
+//   L = s_k - eps3           a lower bound of the exact k-th best score of the prefix, hence of the corpus
+//   F = L - eps1 - margin    a row whose screening score is below F has an exact score below L
+// floor_key = key(F) - 1 so that "key > floor_key" means "score >= F".
+__device__ __forceinline__ void two_stage_floor_of(unsigned long long tau_k, double eps3, double eps1, unsigned long long *floor_key,
+                                                   double *L_out)
+{
+    if (tau_k <= 1ull) {                    // fewer than k rows in the prefix, or a NaN: keep everything (-> overflow -> retry)
+        *floor_key = 0ull;
+        *L_out = -__builtin_huge_val();
+        return;
+    }
+    const double sk = key_score(tau_k);
+    const double L = sk - eps3;
+    const double F = L - eps1 - 1e-9 * (1.0 + fabs(sk));
+    const unsigned long long fk = score_key(F);
+    *floor_key = fk > 2ull ? fk - 1ull : 0ull;
+    *L_out = L;
+}
+
 // RecallSearchService.cs:59-67 with the per-chunk pieces already reduced.
 __device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t created, uint32_t matches,
                                               const QueryConst &qc, int64_t now_ticks)
@@ -116,6 +136,29 @@ __device__ __forceinline__ void wave_merge_sorted(unsigned long long &k, uint32_
     const uint32_t rp = __shfl(op, 63 - lane, 64);
     if (better(rk, rp, k, p)) { k = rk; p = rp; }
     wave_bitonic_merge(k, p, lane);
+}
+
+// One record of a query's result (orr_candidate), or the empty record where the selection ran out of rows.
+__device__ __forceinline__ void write_record(orr_candidate *o, unsigned long long key, uint32_t pos, int b,
+                                             int64_t row_base, const double *dot, const float *dotf, int64_t dot_stride,
+                                             const double *norm_b, const int64_t *created, const int64_t *row_ids,
+                                             const KwView &kw, int32_t dot_exact)
+{
+    orr_candidate c;
+    if (key == 0ull) {
+        c.approx_score = 0.0; c.dot = 0.0; c.norm_b = 0.0; c.created_ticks = 0;
+        c.row_id = -1; c.order_key = -1; c.matches = 0; c.flags = 0;
+    } else {
+        c.approx_score = key_score(key);
+        c.dot = dot ? dot[(int64_t)b * dot_stride + pos] : (dotf ? (double)dotf[(int64_t)b * dot_stride + pos] : 0.0);
+        c.norm_b = norm_b[pos];
+        c.created_ticks = created[pos];
+        c.row_id = row_ids[pos];
+        c.order_key = row_base + (int64_t)pos;
+        c.matches = kw.bitmaps ? (int32_t)kw_matches(kw, b, pos) : 0;
+        c.flags = dot_exact ? ORR_CAND_DOT_EXACT : 0;
+    }
+    *o = c;
 }
 
 }  // namespace orr

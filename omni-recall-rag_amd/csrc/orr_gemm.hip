@@ -506,38 +506,6 @@ __device__ __forceinline__ double exact_dot_of_gathered_rows(const float *__rest
     return acc;
 }
 
-// Two-stage pass, floor: with s_k = the k-th best split-pass score of the sampled prefix,
-//   L = s_k - eps3           a lower bound of the exact k-th best score of the prefix, hence of the corpus
-//   F = L - eps1 - margin    a row whose plain-bf16 score is below F has an exact score below L
-// floor_key[b] = key(F) - 1 so that "key > floor_key" means "score >= F".
-__global__ __launch_bounds__(256) void two_stage_floor_kernel(const unsigned long long *__restrict__ tau_k, int32_t B,
-                                                              double eps3, double eps1,
-                                                              unsigned long long *__restrict__ floor_key,
-                                                              double *__restrict__ L_out)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    if (tau_k[b] <= 1ull) {                 // fewer than k rows in the prefix, or a NaN: keep everything (-> overflow -> retry)
-        floor_key[b] = 0ull;
-        L_out[b] = -__builtin_huge_val();
-        return;
-    }
-    const double sk = key_score(tau_k[b]);
-    const double L = sk - eps3;
-    const double F = L - eps1 - 1e-9 * (1.0 + fabs(sk));
-    const unsigned long long fk = score_key(F);
-    floor_key[b] = fk > 2ull ? fk - 1ull : 0ull;
-    L_out[b] = L;
-}
-
-hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
-                                  unsigned long long *floor_key, double *L_out, hipStream_t s)
-{
-    if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(two_stage_floor_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, tau_k, B, eps3, eps1, floor_key, L_out);
-    return hipGetLastError();
-}
-
 // Two-stage pass, second stage: every buffered (query,row) pair gets its score again from the
 // reference-order fp64 dot (same wave-private swizzled tile walk as K6) and the exact fused
 // formula; the entry's key is overwritten with it.  One wave per 64 buffer entries of a query.
@@ -610,7 +578,7 @@ hipError_t launch_records_dot_from_buffer(const SelEntry *buf, const double *buf
     return hipGetLastError();
 }
 
-// The same for small batches, where this kernel's latency is on the critical path of the call: FOUR lanes per
+// Small batches, where the re-score's latency is on the critical path of the call (finish_survivors_kernel): FOUR lanes per
 // survivor.  The sum's order is fixed (3072 dependent fp64 additions), but the row's bytes need not arrive in
 // that rhythm, and the products (fp32 multiply, widen) are not part of the chain: lane c of a quad holds columns
 // [256 r + 64 c, +64) of round r and forms its 64 products while the other three do the same; then the four
@@ -636,60 +604,174 @@ __device__ __forceinline__ double quad_step(double acc, const double (&prod)[64]
     return quad_broadcast<S>(acc);
 }
 
-__global__ __launch_bounds__(64) void rescore_buffer_exact_quad_kernel(const float *__restrict__ E, int32_t D,
-                                                                       const float *__restrict__ Q,
-                                                                       const double *__restrict__ norm_b,
-                                                                       const int64_t *__restrict__ created, KwView kw,
-                                                                       const QueryConst *__restrict__ qcs, int64_t now_ticks,
-                                                                       const uint32_t *__restrict__ cnt, uint32_t cap,
-                                                                       SelEntry *__restrict__ buf, double *__restrict__ buf_dot)
+// The whole tail of a two-stage pass in ONE launch (up to 64 queries; each launch boundary on this chain costs a
+// one-query search about 10 us of idle GPU): a workgroup of four waves takes 64 survivors of one query,
+//   1. re-scores them as above (16 per wave) and overwrites their keys, dots to buf_dot;
+//   2. sorts its 64 (key, row) pairs into lists[b][y];
+//   3. takes a ticket on done[b]; the workgroup that draws the last one merges the query's lists (four waves, then a
+//      tree through LDS), writes the k' records and the trailer (what select_final_kernel writes), and copies the
+//      records' exact dots out of the buffer (records_dot_from_buffer_kernel).
+// recs may be pinned host memory (the records are final when written); cnt_host (optional, pinned) receives cnt[b].
+__global__ __launch_bounds__(256) void finish_survivors_kernel(const float *__restrict__ E, int32_t D, const float *__restrict__ Q,
+                                                               const double *__restrict__ norm_b, const int64_t *__restrict__ created,
+                                                               const int64_t *__restrict__ row_ids, KwView kw,
+                                                               const QueryConst *__restrict__ qcs, int64_t now_ticks,
+                                                               const uint32_t *__restrict__ cnt, uint32_t *__restrict__ done, uint32_t cap,
+                                                               SelEntry *__restrict__ buf, double *__restrict__ buf_dot,
+                                                               SelEntry *__restrict__ lists, int32_t kprime, int64_t n_rows,
+                                                               int64_t row_base, const double *__restrict__ two_stage_L,
+                                                               orr_candidate *__restrict__ recs, uint32_t *__restrict__ cnt_host)
 {
-    const int lane = threadIdx.x, b = blockIdx.x, c = lane & 3, r16 = lane >> 2;
-    const uint32_t n = cnt[b] < cap ? cnt[b] : cap;
-    const uint32_t first = blockIdx.y * 16u;
-    if (first >= n) return;
-    SelEntry *mine = buf + (int64_t)b * cap + first;
-    const bool live = first + r16 < n;
-    const int64_t my_row = live ? (int64_t)mine[r16].pos : 0;             // quads without a survivor read row 0 and are ignored
-    const float *src = E + my_row * (int64_t)D + c * 64;
-    const float *qsrc = Q + (int64_t)b * D + c * 64;
-    float4 cur[16], qc[16];
+    __shared__ SelEntry sh[4][kSelWidth];
+    __shared__ uint32_t want[kSelWidth];
+    __shared__ uint32_t ticket;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, c = lane & 3, r16 = lane >> 2;
+    const uint32_t total = cnt[b];
+    const uint32_t n = total < cap ? total : cap;
+    const uint32_t active = n ? (n + 63u) / 64u : 1u;          // a query without survivors still gets its (empty) records
+    if (blockIdx.y >= active) return;
+    const uint32_t first = blockIdx.y * 64u;
+    const int64_t n_lists = cap / 64u;
+    unsigned long long k = 0ull;                                   // this wave's running best 64 (finisher)
+    uint32_t p = 0xFFFFFFFFu;
+    if (n) {
+        SelEntry *mine = buf + (int64_t)b * cap + first + wave * 16;
+        const bool live = first + wave * 16 + r16 < n;
+        unsigned long long key = 0ull;
+        uint32_t pos = 0xFFFFFFFFu;
+        if (first + wave * 16 < n) {                            // (whole waves beyond the last survivor skip the dot)
+            const int64_t my_row = live ? (int64_t)mine[r16].pos : 0;          // quads without a survivor read row 0 and are ignored
+            const float *src = E + my_row * (int64_t)D + c * 64;
+            const float *qsrc = Q + (int64_t)b * D + c * 64;
+            float4 cur[16], qc[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        cur[j] = *reinterpret_cast<const float4 *>(src + j * 4);
-        qc[j] = *reinterpret_cast<const float4 *>(qsrc + j * 4);
-    }
-    double acc = 0.0;
-    for (int c0 = 0; c0 < D; c0 += 256) {
-        // the products are not part of the chain: all four lanes of the quad round and widen theirs at once
-        double prod[64];
+            for (int j = 0; j < 16; ++j) {
+                cur[j] = *reinterpret_cast<const float4 *>(src + j * 4);
+                qc[j] = *reinterpret_cast<const float4 *>(qsrc + j * 4);
+            }
+            // what the score needs besides the dot, fetched before the 3072-step chain instead of behind it
+            const QueryConst qc0 = qcs[b];
+            const double nb_row = norm_b[my_row];
+            const int64_t cr_row = created[my_row];
+            const uint32_t m = (qc0.n_terms > 0 && live && c == 0) ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
+            double acc = 0.0;
+            for (int c0 = 0; c0 < D; c0 += 256) {
+                // the products are not part of the chain: all four lanes of the quad round and widen theirs at once
+                double prod[64];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float p0 = qc[j].x * cur[j].x;
-            float p1 = qc[j].y * cur[j].y;
-            float p2 = qc[j].z * cur[j].z;
-            float p3 = qc[j].w * cur[j].w;
-            prod[4 * j + 0] = (double)p0; prod[4 * j + 1] = (double)p1; prod[4 * j + 2] = (double)p2; prod[4 * j + 3] = (double)p3;
+                for (int j = 0; j < 16; ++j) {
+                    float p0 = qc[j].x * cur[j].x;
+                    float p1 = qc[j].y * cur[j].y;
+                    float p2 = qc[j].z * cur[j].z;
+                    float p3 = qc[j].w * cur[j].w;
+                    prod[4 * j + 0] = (double)p0; prod[4 * j + 1] = (double)p1; prod[4 * j + 2] = (double)p2; prod[4 * j + 3] = (double)p3;
+                }
+                const int cn = c0 + 256 < D ? c0 + 256 : c0;                  // clamped, never branched around
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    cur[j] = *reinterpret_cast<const float4 *>(src + cn + j * 4);
+                    qc[j] = *reinterpret_cast<const float4 *>(qsrc + cn + j * 4);
+                }
+                acc = quad_step<0>(acc, prod, c);
+                acc = quad_step<1>(acc, prod, c);
+                acc = quad_step<2>(acc, prod, c);
+                acc = quad_step<3>(acc, prod, c);
+            }
+            if (live && c == 0) {
+                QueryConst exact = qc0;
+                exact.use_cos = 1;                               // this path only runs with cosine; guards are inside fused_score
+                key = score_key(fused_score(acc, nb_row, cr_row, m, exact, now_ticks));
+                pos = (uint32_t)my_row;
+                mine[r16].key = key;
+                mine[r16].pad = m;                               // the record's matches (below)
+                buf_dot[(int64_t)b * cap + first + wave * 16 + r16] = acc;   // ... and its exact dot
+            }
         }
-        const int cn = c0 + 256 < D ? c0 + 256 : c0;                      // clamped, never branched around
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            cur[j] = *reinterpret_cast<const float4 *>(src + cn + j * 4);
-            qc[j] = *reinterpret_cast<const float4 *>(qsrc + cn + j * 4);
+        if (c == 0) { sh[0][wave * 16 + r16].key = key; sh[0][wave * 16 + r16].pos = pos; }
+        __syncthreads();
+        if (wave == 0) {
+            k = sh[0][lane].key;
+            p = sh[0][lane].pos;
+            wave_sort(k, p, lane);
+            if (active > 1u) {
+                SelEntry o;
+                o.key = k; o.pos = p; o.pad = 0;
+                lists[((int64_t)b * n_lists + blockIdx.y) * kSelWidth + lane] = o;
+            }
         }
-        acc = quad_step<0>(acc, prod, c);
-        acc = quad_step<1>(acc, prod, c);
-        acc = quad_step<2>(acc, prod, c);
-        acc = quad_step<3>(acc, prod, c);
     }
-    if (live && c == 0) {
-        const QueryConst qc0 = qcs[b];
-        const uint32_t m = qc0.n_terms > 0 ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
-        QueryConst exact = qc0;
-        exact.use_cos = 1;
-        mine[r16].key = score_key(fused_score(acc, norm_b[my_row], created[my_row], m, exact, now_ticks));
-        buf_dot[(int64_t)b * cap + first + r16] = acc;
+    if (active > 1u) {
+        // ---- the last workgroup of the query finishes it (every thread's writes are visible device-wide before the ticket);
+        // a query with at most 64 survivors is finished by its only workgroup from the list it holds
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) ticket = atomicAdd(&done[b], 1u);
+        __syncthreads();
+        if (ticket != active - 1u) return;
+        __threadfence();
+        k = 0ull;
+        p = 0xFFFFFFFFu;
+        for (uint32_t l = (uint32_t)wave; l < active; l += 4u) {
+            const SelEntry e = lists[((int64_t)b * n_lists + l) * kSelWidth + lane];
+            wave_merge_sorted(k, p, e.key, e.pos, lane);
+        }
     }
+    __syncthreads();                                               // (sh[0] was read by wave 0 above)
+    sh[wave][lane].key = k;
+    sh[wave][lane].pos = p;
+    __syncthreads();
+#pragma unroll
+    for (int stride = 2; stride > 0; stride >>= 1) {
+        if (wave < stride) {
+            wave_merge_sorted(k, p, sh[wave + stride][lane].key, sh[wave + stride][lane].pos, lane);
+            sh[wave][lane].key = k;
+            sh[wave][lane].pos = p;
+        }
+        __syncthreads();
+    }
+    orr_candidate *o = recs + (int64_t)b * (kprime + 1);
+    if (wave == 0) {
+        if (lane < kprime)
+            write_record(o + lane, k, p, b, row_base, nullptr, nullptr, 0, norm_b, created, row_ids, KwView{nullptr, 0, nullptr, nullptr}, 0);   // matches: below
+        want[lane] = (lane < kprime && k != 0ull) ? p : 0xFFFFFFFFu;
+        const unsigned long long valid_mask = __ballot(k != 0ull && lane < kprime);
+        const int n_valid = __popcll(valid_mask);
+        const unsigned long long worst_key = __shfl(k, (n_valid > 0 ? n_valid - 1 : 0), 64);
+        if (lane == 0) {
+            orr_candidate t;
+            // every buffered row became a record -> the only rows left out are below L
+            const bool kept_all = n_rows <= (int64_t)kprime || total <= (uint32_t)kprime;
+            t.approx_score = (kept_all || n_valid == 0) ? -__builtin_huge_val() : key_score(worst_key);
+            t.dot = 0.0; t.norm_b = two_stage_L[b]; t.created_ticks = 0;
+            t.row_id = -1; t.order_key = n_rows; t.matches = n_valid; t.flags = ORR_CAND_TRAILER | ORR_CAND_TWO_STAGE;
+            if (total > cap) t.flags |= ORR_CAND_OVERFLOW;
+            o[kprime] = t;
+            if (cnt_host) cnt_host[b] = total;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = (uint32_t)tid; i < n; i += 256u) {
+        const SelEntry e = buf[(int64_t)b * cap + i];
+        for (int r = 0; r < kprime; ++r)
+            if (want[r] == e.pos) {                                // a row occurs once in a buffer
+                o[r].dot = buf_dot[(int64_t)b * cap + i];
+                o[r].matches = (int32_t)e.pad;
+                o[r].flags = ORR_CAND_DOT_EXACT;
+            }
+    }
+}
+
+hipError_t launch_finish_survivors(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b, const int64_t *created,
+                                   const int64_t *row_ids, KwView kw, const QueryConst *qc, int64_t now_ticks, const uint32_t *cnt,
+                                   uint32_t *done, uint32_t cap, SelEntry *buf, double *buf_dot, SelEntry *lists, int32_t kprime,
+                                   int64_t n_rows, int64_t row_base, const double *two_stage_L, orr_candidate *recs, uint32_t *cnt_host,
+                                   hipStream_t s)
+{
+    if (B <= 0) return hipSuccess;
+    if (D % 256 != 0 || cap % 64 != 0 || kprime < 1 || kprime > kSelWidth || !two_stage_L) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(finish_survivors_kernel, dim3((unsigned)B, cap / 64), dim3(256), 0, s, E, D, Q, norm_b, created, row_ids, kw, qc,
+                       now_ticks, cnt, done, cap, buf, buf_dot, lists, kprime, n_rows, row_base, two_stage_L, recs, cnt_host);
+    return hipGetLastError();
 }
 
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
@@ -698,14 +780,9 @@ hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q
 {
     if (B <= 0) return hipSuccess;
     if (D % 64 != 0) return hipErrorInvalidValue;
-    // four lanes per survivor while the kernel's latency is on the critical path of the call (small batches), one row per
-    // lane beyond (measured crossover: 64 queries)
-    if (D % 256 == 0 && B <= 64)
-        hipLaunchKernelGGL(rescore_buffer_exact_quad_kernel, dim3((unsigned)B, cap / 16), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
-                           now_ticks, cnt, cap, buf, buf_dot);
-    else
-        hipLaunchKernelGGL(rescore_buffer_exact_kernel<false>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
-                           now_ticks, cnt, cap, buf, buf_dot);
+    // one row per lane (large batches; up to 64 queries go through launch_finish_survivors, four lanes per survivor)
+    hipLaunchKernelGGL(rescore_buffer_exact_kernel<false>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
+                       now_ticks, cnt, cap, buf, buf_dot);
     return hipGetLastError();
 }
 

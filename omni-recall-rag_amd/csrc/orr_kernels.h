@@ -200,11 +200,16 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
 hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, float *S,
                                  int64_t s_stride, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
-hipError_t launch_two_stage_floor(const unsigned long long *tau_k, int32_t B, double eps3, double eps1,
-                                  unsigned long long *floor_key, double *L_out, hipStream_t s);
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
                                        const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
                                        const uint32_t *cnt, uint32_t cap, SelEntry *buf, double *buf_dot, hipStream_t s);
+// Up to 64 queries, D % 256 == 0: re-score + lists + final selection + records with exact dots in one launch (done: [B]
+// zeroed counters; recs / cnt_host may be pinned host memory).
+hipError_t launch_finish_survivors(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b, const int64_t *created,
+                                   const int64_t *row_ids, KwView kw, const QueryConst *qc, int64_t now_ticks, const uint32_t *cnt,
+                                   uint32_t *done, uint32_t cap, SelEntry *buf, double *buf_dot, SelEntry *lists, int32_t kprime,
+                                   int64_t n_rows, int64_t row_base, const double *two_stage_L, orr_candidate *recs, uint32_t *cnt_host,
+                                   hipStream_t s);
 hipError_t launch_records_dot_from_buffer(const SelEntry *buf, const double *buf_dot, const uint32_t *cnt, uint32_t cap, int32_t B,
                                           int32_t kprime, int64_t row_base, orr_candidate *recs, hipStream_t s);
 hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint32_t cap, int32_t B, int32_t seg_first,
@@ -219,8 +224,14 @@ hipError_t launch_rescore_exact(const float *E, int32_t D, const float *Q, int32
 
 // Sampling pass of the batched selection: tau_out[b] = k'-th best key among the first sample_seg
 // lists of query b (0 if there are fewer).
+// floor (optional): the two-stage floor of that key in the same launch (floor_key[b], L[b]; two_stage_floor_of, orr_device.h).
+struct FloorOut {
+    unsigned long long *floor_key = nullptr;
+    double *L = nullptr;
+    double eps3 = 0.0, eps1 = 0.0;
+};
 hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
-                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s);
+                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor = FloorOut());
 
 // Generic path for large k: keys[r] = score key of (query b,row r), vals[r] = r.
 hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,

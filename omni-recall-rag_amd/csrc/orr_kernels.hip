@@ -660,28 +660,6 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
     return hipGetLastError();
 }
 
-__device__ __forceinline__ void write_record(orr_candidate *o, unsigned long long key, uint32_t pos, int b,
-                                             int64_t row_base, const double *dot, const float *dotf, int64_t dot_stride,
-                                             const double *norm_b, const int64_t *created, const int64_t *row_ids,
-                                             const KwView &kw, int32_t dot_exact)
-{
-    orr_candidate c;
-    if (key == 0ull) {
-        c.approx_score = 0.0; c.dot = 0.0; c.norm_b = 0.0; c.created_ticks = 0;
-        c.row_id = -1; c.order_key = -1; c.matches = 0; c.flags = 0;
-    } else {
-        c.approx_score = key_score(key);
-        c.dot = dot ? dot[(int64_t)b * dot_stride + pos] : (dotf ? (double)dotf[(int64_t)b * dot_stride + pos] : 0.0);
-        c.norm_b = norm_b[pos];
-        c.created_ticks = created[pos];
-        c.row_id = row_ids[pos];
-        c.order_key = row_base + (int64_t)pos;
-        c.matches = kw.bitmaps ? (int32_t)kw_matches(kw, b, pos) : 0;
-        c.flags = dot_exact ? ORR_CAND_DOT_EXACT : 0;
-    }
-    *o = c;
-}
-
 // ---------------------------------------------------------------------------
 // K5b  final merge per query: 16 waves fold the n_seg sorted lists, then a
 // 4-level tree through LDS; wave 0 writes kprime records and the trailer.
@@ -697,7 +675,7 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
                                                             unsigned long long *__restrict__ tau_out,
                                                             const uint32_t *__restrict__ fused_cnt, uint32_t fused_cap,
                                                             const double *__restrict__ two_stage_L,
-                                                            orr_candidate *__restrict__ out)
+                                                            orr_candidate *__restrict__ out, FloorOut floor)
 {
     __shared__ SelEntry lists[16][kSelWidth];
     const int lane = threadIdx.x & 63;
@@ -736,7 +714,10 @@ __global__ __launch_bounds__(1024) void select_final_kernel(const SelEntry *__re
     }
     if (wave == 0 && tau_out) {      // sampling pass: only the k'-th best key of these lists is wanted
         const unsigned long long kth = __shfl(k, kprime - 1, 64);
-        if (lane == 0) tau_out[b] = kth;          // 0 (empty slot) if fewer than k' rows: no filtering
+        if (lane == 0) {
+            tau_out[b] = kth;                     // 0 (empty slot) if fewer than k' rows: no filtering
+            if (floor.floor_key) two_stage_floor_of(kth, floor.eps3, floor.eps1, floor.floor_key + b, floor.L + b);
+        }
         return;
     }
     if (wave == 0) {
@@ -770,19 +751,19 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
     if (B <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, n_seg, n_seg, kprime, n_rows, row_base,
-                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, fused_cnt, fused_cap, two_stage_L, out);
+                       dot, dotf, dot_stride, norm_b, created, row_ids, kw, dot_exact, approx_eps, tau_out, fused_cnt, fused_cap, two_stage_L, out, FloorOut());
     return hipGetLastError();
 }
 
 hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
-                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s)
+                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor)
 {
     if (B <= 0 || sample_seg <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
     const KwView nokw{nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, sample_seg, n_seg_total, kprime,
                        (int64_t)0, (int64_t)0, nullptr, nullptr, (int64_t)0, nullptr, nullptr, nullptr, nokw, 0, 0.0,
-                       tau_out, nullptr, 0u, nullptr, nullptr);
+                       tau_out, nullptr, 0u, nullptr, nullptr, floor);
     return hipGetLastError();
 }
 

@@ -447,11 +447,17 @@ struct I8Queries {
     const double *err2;         // [B] |q - q^|^2
 };
 
-template <int NQ, bool LOWER>
+// JR: 16-row groups per unit of work (one wave streams a unit's D columns in stages of eight 16-byte loads per lane:
+// 8/JR k-tiles of JR groups).  8 for the pass over all rows (long sequential streams, few epilogues); 1 for the sampled
+// prefix, whose few thousand rows then spread over hundreds of waves instead of a few dozen (2 x 4096 rows x 3072:
+// 34 -> 6 us, and that launch is on the critical path of a one-query search).
+template <int NQ, bool LOWER, int JR>
 __global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int32_t D, I8Rows R, int64_t n_units, int64_t n_rows,
                                                                 FusedEpilogue epi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lq[];     // [2][NQ][D] int8
+    constexpr int KS = 8 / JR;                     // k-tiles per stage
+    constexpr int UPT = 16 / JR;                   // units per 256-row tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid * 16; i < NQ * D; i += 256 * 16) {
         *reinterpret_cast<uint4 *>(lq + i) = *reinterpret_cast<const uint4 *>(Q.q1 + i);
@@ -462,51 +468,57 @@ __global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int
     const int KT = D / 64;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < n_units; u += (int64_t)gridDim.x * 4) {
-        const int8_t *base = R.tiled + ((u >> 1) * KT) * (int64_t)(256 * 64) + (u & 1) * (128 * 64) + lane * 16;
-        int a1[NQ][8], a2[NQ][8];
+        const int8_t *base = R.tiled + ((u / UPT) * KT) * (int64_t)(256 * 64) + (u % UPT) * (JR * 1024) + lane * 16;
+        int a1[NQ][JR], a2[NQ][JR];
 #pragma unroll
         for (int b = 0; b < NQ; ++b)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { a1[b][j] = 0; a2[b][j] = 0; }
+            for (int j = 0; j < JR; ++j) { a1[b][j] = 0; a2[b][j] = 0; }
         i32x4 s0[8], s1[8];
 #define ORR_LOAD8(st, kt) { \
-        const int8_t *p_ = base + (int64_t)(kt) * (256 * 64); \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) st[j] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p_ + j * 1024)); }
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) { \
+            const int8_t *p_ = base + (int64_t)((kt) + ks) * (256 * 64); \
+            _Pragma("unroll") for (int j = 0; j < JR; ++j) \
+                st[ks * JR + j] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p_ + j * 1024)); } }
 #define ORR_DOT8(st, kt) { \
         _Pragma("unroll") for (int b = 0; b < NQ; ++b) { \
-            const i32x4 qa = *reinterpret_cast<const i32x4 *>(lq + (size_t)b * D + (kt) * 64 + c * 16); \
-            const i32x4 qb = *reinterpret_cast<const i32x4 *>(lq + (size_t)(NQ + b) * D + (kt) * 64 + c * 16); \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) { \
-                _Pragma("unroll") for (int w = 0; w < 4; ++w) { \
-                    a1[b][j] = __builtin_amdgcn_sdot4(st[j][w], qa[w], a1[b][j], false); \
-                    a2[b][j] = __builtin_amdgcn_sdot4(st[j][w], qb[w], a2[b][j], false); } } } }
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) { \
+                const i32x4 qa = *reinterpret_cast<const i32x4 *>(lq + (size_t)b * D + ((kt) + ks) * 64 + c * 16); \
+                const i32x4 qb = *reinterpret_cast<const i32x4 *>(lq + (size_t)(NQ + b) * D + ((kt) + ks) * 64 + c * 16); \
+                _Pragma("unroll") for (int j = 0; j < JR; ++j) { \
+                    _Pragma("unroll") for (int w = 0; w < 4; ++w) { \
+                        a1[b][j] = __builtin_amdgcn_sdot4(st[ks * JR + j][w], qa[w], a1[b][j], false); \
+                        a2[b][j] = __builtin_amdgcn_sdot4(st[ks * JR + j][w], qb[w], a2[b][j], false); } } } } }
         ORR_LOAD8(s0, 0)
-        for (int kt = 0; kt < KT; kt += 2) {                                // D % 128 == 0
-            ORR_LOAD8(s1, kt + 1)
+        for (int kt = 0; kt < KT; kt += 2 * KS) {                           // KT % (2 KS) == 0 (checked by the launcher)
+            ORR_LOAD8(s1, kt + KS)
             ORR_DOT8(s0, kt)
-            ORR_LOAD8(s0, (kt + 2 < KT ? kt + 2 : KT - 1))                   // clamped, never branched around
-            ORR_DOT8(s1, kt + 1)
+            ORR_LOAD8(s0, (kt + 2 * KS < KT ? kt + 2 * KS : KT - KS))        // clamped, never branched around
+            ORR_DOT8(s1, kt + KS)
         }
 #undef ORR_DOT8
 #undef ORR_LOAD8
 #pragma unroll
         for (int b = 0; b < NQ; ++b)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < JR; ++j) {
                 a1[b][j] += __shfl_xor(a1[b][j], 1, 64); a1[b][j] += __shfl_xor(a1[b][j], 2, 64);
                 a2[b][j] += __shfl_xor(a2[b][j], 1, 64); a2[b][j] += __shfl_xor(a2[b][j], 2, 64);
             }
         const int sl = lane & 3;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int64_t row = (u >> 1) * kScBN + (u & 1) * 128 + 16 * (jj * 4 + sl) + (lane >> 2);
+        for (int jj = 0; jj < (JR + 3) / 4; ++jj) {
+            if (jj * 4 + sl >= JR) continue;
+            const int64_t row = (u / UPT) * kScBN + (u % UPT) * (16 * JR) + 16 * (jj * 4 + sl) + (lane >> 2);
             if (row >= n_rows) continue;
             const double2 rc = epi.rowc[row];
             const double se = (double)R.scale[row], re = (double)R.rel_err[row], rh = (double)R.rel_hat[row];
 #pragma unroll
             for (int b = 0; b < NQ; ++b) {
-                const int i1 = sl == 0 ? a1[b][jj * 4] : sl == 1 ? a1[b][jj * 4 + 1] : sl == 2 ? a1[b][jj * 4 + 2] : a1[b][jj * 4 + 3];
-                const int i2 = sl == 0 ? a2[b][jj * 4] : sl == 1 ? a2[b][jj * 4 + 1] : sl == 2 ? a2[b][jj * 4 + 2] : a2[b][jj * 4 + 3];
+                int i1 = a1[b][jj * 4], i2 = a2[b][jj * 4];
+#pragma unroll
+                for (int t = 1; t < 4; ++t)
+                    if (jj * 4 + t < JR && sl == t) { i1 = a1[b][jj * 4 + t < JR ? jj * 4 + t : 0]; i2 = a2[b][jj * 4 + t < JR ? jj * 4 + t : 0]; }
                 const QueryConst qc = epi.qc[b];
                 const double dot = se * (double)Q.s1[b] * ((double)i1 + (double)i2 * (1.0 / 254.0));
                 // |cos error| <= (|q|/sqrt(normA)) re + (|q - q^|/sqrt(normA)) rh ; the first factor is 1 up to 2^-23
@@ -854,7 +866,11 @@ hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double 
 {
     if (B <= 0 || n_rows <= 0) return hipSuccess;
     if (B > kMaxGemvScreenQ || D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
-    const int64_t n_units = ((n_rows + kScBN - 1) / kScBN) * 2;
+    // the sampled prefix (lower_bound) is a few thousand rows on the critical path of the call: 16-row units spread it over
+    // hundreds of waves; the pass over all rows streams 128-row units
+    const bool fine = lower_bound && D % 1024 == 0;
+    const int64_t tiles = (n_rows + kScBN - 1) / kScBN;
+    const int64_t n_units = tiles * (fine ? 16 : 2);
     const int64_t blocks = std::min<int64_t>((n_units + 3) / 4, 512);
     const int8_t *q1 = static_cast<const int8_t *>(q12), *q2 = q1 + (size_t)B * D;
     I8Rows Rd{static_cast<const int8_t *>(tiled), scale, rel_err, rel_hat};
@@ -866,8 +882,9 @@ hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double 
         FusedEpilogue e2 = epi;                              // everything the kernel indexes by query, shifted to b0
         e2.qc += b0; e2.tau += b0; e2.cnt += b0; e2.buf += (size_t)b0 * epi.cap;
         if (e2.kw.q_term_off) e2.kw.q_term_off += b0;
-#define ORR_I8(NQ) do { if (lower_bound) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
-                        else hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, false>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); } while (0)
+#define ORR_I8(NQ) do { if (fine) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true, 1>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
+                        else if (lower_bound) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true, 8>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
+                        else hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, false, 8>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); } while (0)
         switch (nb) {
         case 1: ORR_I8(1); break;
         case 2: ORR_I8(2); break;

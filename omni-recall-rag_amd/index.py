@@ -207,8 +207,9 @@ class RecallIndex:
         N.check(N.hip.orr_index_screen_dots(self._h, int(q.shape[0]), int(q.shape[1]), _ptr(q), _ptr(out)))
         return out
 
-    def set_profiling(self, on: bool) -> None:
-        N.check(N.hip.orr_index_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on) -> None:
+        """False/0 off, True/1 every kernel, 2 only the launch that streams every row (orr_index_set_profiling)."""
+        N.check(N.hip.orr_index_set_profiling(self._h, int(on)))
 
     def search_stats(self, reset: bool = False) -> dict:
         """orr_index_search_stats: repeats of the cheap passes and what the screening pass kept, since the last reset."""

@@ -1,13 +1,11 @@
-mkdir -p gpurun_out/r2
-for rep in 1 2 3; do for v in "" _vns; do
-  export ORR_HIP_LIB=$PWD/omni-recall-rag_amd/libomnirecall_hip$v.so
-  timeout -k 10 100 python bench.py --no-legs --no-cpu-baseline --rows-per-gpu 1000000 --batch 256 > gpurun_out/r2/bv$v.json 2>/dev/null
-  python - <<EOF
+mkdir -p gpurun_out/r2/tl2
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2/t_all.log 2>&1; tail -3 gpurun_out/r2/t_all.log
+ORR_HOST_TIMING=1 timeout -k 10 300 python bench.py --no-legs --no-cpu-baseline --rows-per-gpu 1000000 --batch 1 --steps 256 --warmup 10 > gpurun_out/r2/b1.json 2> gpurun_out/r2/b1.err
+tail -1 gpurun_out/r2/b1.err
+python - <<EOF
 import json
-d=json.load(open("gpurun_out/r2/bv$v.json")); print("variant '$v'", round(d["value"]), round(d["ms_per_step"],4), round(d["roofline"]["avg_launch_ms"],4), d["rank1_is_planted_row"])
+d=json.load(open("gpurun_out/r2/b1.json"))
+print(round(d["value"]), d["ms_per_step"], {n: round(x["avg_ms"],4) for n,x in d["kernels"].items()})
 EOF
-done; done
-unset ORR_HIP_LIB
-timeout -k 10 100 python bench.py --no-legs --no-cpu-baseline --rows-per-gpu 1000000 --batch 1024 > gpurun_out/r2/b1024.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/r2/b1024.json')); print('b1024', round(d['value']), d['ms_per_step'], d['roofline']['avg_launch_ms'])"
-timeout -k 10 600 python -m pytest tests/test_gpu_scale.py tests/test_gpu_parity.py -m gpu -x -q > gpurun_out/r2/t1.log 2>&1; tail -3 gpurun_out/r2/t1.log
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2/tl2 -o b1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-legs --no-cpu-baseline --rows-per-gpu 1000000 --batch 1 --steps 20 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/r2/tl2/bench.json 2>$GRAFT_REPO_ROOT/gpurun_out/r2/tl2/err.log
