@@ -1408,6 +1408,19 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         if (q_host && !dev_norms) *q_host = idx->pin_q.as<float>();
     }
 
+    // 1..4 queries on the int8 shadow: their int8 images are the first thing the main stream needs and depend on nothing
+    // else, so that launch goes out before the host prepares the keyword side; it also clears the pass's counters
+    bool counters_cleared = false;
+    if (n > 0 && ts_stream && ts_i8) {
+        ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
+        ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
+        ORR_TRY(idx->ws_q8err.reserve(sizeof(double) * (size_t)B));
+        ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * 3 * (size_t)B));
+        HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s, nullptr,
+                                       idx->ws_fcnt.as<uint32_t>(), 3 * B));
+        counters_cleared = true;
+    }
+
     if (n == 0) {   // nothing on this shard takes part: empty records + trailers
         std::vector<orr_candidate> empty(rec_count);
         for (auto &c : empty) { memset(&c, 0, sizeof(c)); c.row_id = -1; c.order_key = -1; }
@@ -1512,6 +1525,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         bm_clean_before = bm_clean;
         ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
         ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
+        ORR_TRY(idx->pin_kwcnt.reserve(sizeof(unsigned long long)));
+        *idx->pin_kwcnt.as<unsigned long long>() = 0ull;
         hipStream_t k = idx->stream_kw;
         uint8_t *dm = idx->ws_meta.as<uint8_t>();
         HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
@@ -1542,11 +1557,10 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             {
                 Timed t(idx, "expand_hits", 0.0, k);
                 HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
-                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k));
+                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k,
+                                                idx->pin_kwcnt.as<unsigned long long>()));     // hits of this pass: statistics
             }
         }
-        ORR_TRY(idx->pin_kwcnt.reserve(sizeof(unsigned long long)));
-        HIP_TRY(hipMemcpyAsync(idx->pin_kwcnt.p, idx->ws_counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, k));   // hits of this pass: statistics
         HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
         kw.bitmaps = idx->ws_bitmaps.as<uint32_t>();
         kw.words_per_term = words;
@@ -1587,10 +1601,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             fused_sample_seg = sample_segments(n_seg_all, n, a.topk, true, idx->sample_boost);
             dotf_rows = (int64_t)fused_sample_seg * orr::kSelSegRows;
             if (ts_i8) {
-                ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * idx->dim));
-                ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
-                ORR_TRY(idx->ws_q8err.reserve(sizeof(double) * (size_t)B));
-                HIP_TRY(orr::launch_i8_queries(d_q, B, idx->dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s));
+                // (quantised above, before the keyword side was prepared)
             } else {
                 ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
                 HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
@@ -1695,7 +1706,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     }
     // per-row selection constants do not depend on the keyword side: enqueued before the main stream waits for it
     const double2 *d_rowc_early = nullptr;
-    if (batched_score && kprime <= orr::kSelWidth) {
+    const bool rowc_inline = ts_stream && ts_i8;        // the int8 stream forms them in its epilogue (one or two uses per row)
+    if (batched_score && kprime <= orr::kSelWidth && !rowc_inline) {
         ORR_TRY(idx->ws_rowc.reserve(sizeof(double2) * (size_t)n));
         Timed t(idx, "row_consts", 32.0 * (double)n);
         HIP_TRY(orr::launch_row_consts(idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->ws_rowc.as<double2>(), s));
@@ -1747,7 +1759,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             epi.qf = idx->ws_fqf.as<float4>();
             epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw;
             epi.cnt = idx->ws_fcnt.as<uint32_t>(); epi.buf = idx->ws_fbuf.as<orr::SelEntry>(); epi.cap = kCap;
-            HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * 3 * (size_t)B, s));
+            if (!counters_cleared) HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * 3 * (size_t)B, s));
             if (two_stage) {
                 // ---- two-stage: floor from the k-th best split-pass score of the prefix; ONE plain-bf16
                 // product over ALL rows keeps every row that can still reach it; those are re-scored
@@ -1779,22 +1791,27 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     pre.tau = idx->ws_zero.as<unsigned long long>();
                     pre.buf = idx->ws_pbuf.as<orr::SelEntry>();
                     pre.cap = cap_p;
-                    pre.cnt = idx->ws_fcnt.as<uint32_t>() + B;         // its own counters: one memset for both launches
+                    pre.cnt = idx->ws_fcnt.as<uint32_t>() + B;         // its own counters: one clearing for both launches
+                    const int64_t pre_rows = std::min<int64_t>(dotf_rows, n);
+                    const bool pre_lists = ts_i8 && orr::screen_gemv_i8_prefix_makes_lists(idx->dim);   // sorted lists straight from the kernel
+                    ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
+                    if (pre_lists) pre.buf = idx->ws_psel.as<orr::SelEntry>();
                     {
                         Timed t(idx, "screen_gemv_prefix", (ts_i8 ? 1.0 : 2.0) * (double)dotf_rows * idx->dim + 2.0 * (double)B * idx->dim);
                         if (ts_i8)
                             HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
                                                                idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(),
-                                                               std::min<int64_t>(dotf_rows, n), idx->dim, pre, true, s));
+                                                               idx->d_norm_b, idx->d_created, a.now_ticks, pre_rows, idx->dim, pre, true, s));
                         else
-                            HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, std::min<int64_t>(dotf_rows, n), idx->dim, pre, s));
+                            HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, pre_rows, idx->dim, pre, s));
                     }
-                    {   // lists of 64 sorted in parallel, then the k-th best key per query
+                    {   // lists of 64 sorted in parallel (by the int8 stream itself where it can), then the k-th best key per query
                         Timed t(idx, "select_floor", 0.0);
-                        const int32_t lists_p = (int32_t)(cap_p / orr::kSelWidth);
-                        ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
-                        HIP_TRY(orr::launch_buffer_to_lists(pre.buf, pre.cnt, cap_p, B, 0, lists_p, idx->ws_psel.as<orr::SelEntry>(), s));
-                        HIP_TRY(orr::launch_select_final_sample(idx->ws_psel.as<orr::SelEntry>(), lists_p, lists_p, B, kth, d_tau, s, floor));
+                        const int32_t lists_all = (int32_t)(cap_p / orr::kSelWidth);
+                        const int32_t lists_p = pre_lists ? (int32_t)((pre_rows + orr::kSelWidth - 1) / orr::kSelWidth) : lists_all;
+                        if (!pre_lists)
+                            HIP_TRY(orr::launch_buffer_to_lists(pre.buf, pre.cnt, cap_p, B, 0, lists_all, idx->ws_psel.as<orr::SelEntry>(), s));
+                        HIP_TRY(orr::launch_select_final_sample(idx->ws_psel.as<orr::SelEntry>(), lists_all, lists_p, B, kth, d_tau, s, floor));
                     }
                 } else {
                     Timed t(idx, "select_floor", 0.0);
@@ -1837,8 +1854,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 } else if (ts_i8) {
                     Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 12.0 * (double)n + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
-                                                       idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(), n,
-                                                       idx->dim, epi, false, s));
+                                                       idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(),
+                                                       idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->dim, epi, false, s));
                 } else if (ts_gemv) {
                     Timed t(idx, "screen_gemv_bf16", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, n, idx->dim, epi, s));

@@ -68,6 +68,18 @@ __device__ __forceinline__ double fused_score(double dot, double norm_b, int64_t
 // 1/sqrt(normB)) are computed once per batch (row_consts_kernel), per-query 1/sqrt(normA) on
 // the host.  It differs from fused_score by a few ulp (reciprocal-multiply instead of divide),
 // far inside the certificate's slack; the survivors are always re-scored exactly on the host.
+// The per-row pieces of fused_score_fast: {1/sqrt(normB) or 0, recency * 0.1} (row_consts_kernel stores them once per
+// batch; the streaming screen of 1..4 queries forms them where it needs them).
+__device__ __forceinline__ double2 row_consts_of(double nb, int64_t created, int64_t now_ticks)
+{
+    const double total_days = (double)(now_ticks - created) / 864000000000.0;
+    const double age_days = total_days > 0.0 ? total_days : 0.0;
+    double2 o;
+    o.x = nb <= 0.0 ? 0.0 : 1.0 / sqrt(nb);              // NaN stays NaN
+    o.y = exp(-age_days / 30.0) * 0.1;
+    return o;
+}
+
 __device__ __forceinline__ double fused_score_fast(double dot, double inv_sqrt_nb, double rec01, uint32_t matches,
                                                    const QueryConst &qc)
 {

@@ -92,8 +92,10 @@ constexpr int kMatchGroup = 32;       // terms per workgroup (grid.y)
 hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
                                     const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
                                     unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
+// counter_host (optional, pinned host memory): receives *counter (hits << 32 | chunks) for the caller's statistics.
 hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
-                              const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s);
+                              const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s,
+                              unsigned long long *counter_host = nullptr);
 
 // Per-query constants of the fused score.
 struct QueryConst {
@@ -185,10 +187,16 @@ hipError_t launch_screen_gemv_bf16(const void *q_hi, int32_t B, const void *e_sh
 size_t i8_tiled_bytes(int64_t n_rows, int32_t D);
 hipError_t launch_i8_shadow(const float *E, const double *norm_b, int64_t n_rows, int32_t D, void *tiled, float *scale,
                             float *rel_err, float *rel_hat, hipStream_t s);
+// zero (optional): n_zero words the kernel clears as well (the pass's counters: saves the call a memset).
 hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s,
-                             double *err2_level1 = nullptr);
+                             double *err2_level1 = nullptr, uint32_t *zero = nullptr, int32_t n_zero = 0);
+// norm_b / created / now_ticks: not null -> the kernel forms each row's scoring constants itself (epi.rowc unused).
+// lower_bound with screen_gemv_i8_prefix_makes_lists(D): epi.tau must be all 0 and the keys leave as sorted lists of 64
+// in epi.buf[b][0 .. ceil(n_rows / 64) * 64) (epi.cnt unused); otherwise survivors are appended to epi.buf through epi.cnt.
+bool screen_gemv_i8_prefix_makes_lists(int32_t D);
 hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double *err2, int32_t B, const void *tiled,
-                                 const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, int32_t D,
+                                 const float *scale, const float *rel_err, const float *rel_hat, const double *norm_b,
+                                 const int64_t *created, int64_t now_ticks, int64_t n_rows, int32_t D,
                                  const FusedEpilogue &epi, bool lower_bound, hipStream_t s);
 // K2j: the screening GEMM on the int8 shadow (v_mfma_i32_32x32x32_i8: twice the bf16 rate, half its bytes).
 // Queries: ONE int8 level (q1 of launch_i8_queries, err2_l1), tiled like the rows; epi must carry i8_rowf / i8_qs1.

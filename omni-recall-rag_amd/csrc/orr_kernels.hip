@@ -25,13 +25,7 @@ __global__ __launch_bounds__(256) void row_consts_kernel(const double *__restric
                                                          int64_t n_rows, double2 *__restrict__ out)
 {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
-        const double nb = norm_b[r];
-        const double total_days = (double)(now_ticks - created[r]) / 864000000000.0;
-        const double age_days = total_days > 0.0 ? total_days : 0.0;
-        double2 o;
-        o.x = nb <= 0.0 ? 0.0 : 1.0 / sqrt(nb);          // NaN stays NaN
-        o.y = exp(-age_days / 30.0) * 0.1;
-        out[r] = o;
+        out[r] = row_consts_of(norm_b[r], created[r], now_ticks);
     }
 }
 
@@ -407,10 +401,12 @@ __global__ __launch_bounds__(256) void vocab_hits_kernel(const uint16_t *__restr
 __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restrict__ hits,
                                                           const unsigned long long *__restrict__ counter,
                                                           uint32_t max_hits, const uint32_t *__restrict__ post_rows,
-                                                          uint32_t *__restrict__ bitmaps, int64_t words_per_term)
+                                                          uint32_t *__restrict__ bitmaps, int64_t words_per_term,
+                                                          unsigned long long *__restrict__ counter_host)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long cnt = *counter;
+    if (counter_host && blockIdx.x == 0 && threadIdx.x == 0) *counter_host = cnt;      // statistics (pinned host memory)
     uint32_t n_hits = (uint32_t)(cnt >> 32);
     if (n_hits > max_hits) n_hits = max_hits;       // overflow is detected and retried by the host
     const uint32_t n_chunks = (uint32_t)cnt;
@@ -428,19 +424,29 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restric
         uint32_t *bm = bitmaps + (int64_t)h.term * words_per_term;
         // posting rows ascend, so the lanes that hit one bitmap word are neighbours: OR their bits
         // together (segmented, 5 steps: a word has 32 bits) and let the last lane of each run do the atomic
-        for (uint64_t p0 = b0; p0 < b1; p0 += 64) {
-            const uint64_t p = p0 + lane;
-            const bool live = p < b1;
-            const uint32_t row = live ? post_rows[p] : 0xFFFFFFFFu;
-            const uint32_t word = row >> 5;
-            uint32_t bits = live ? 1u << (row & 31) : 0u;
+        // (four groups of 64 postings in flight: a one-query search has a handful of chunks, each a chain of
+        // load -> atomic round trips otherwise)
+        for (uint64_t p0 = b0; p0 < b1; p0 += 256) {
+            uint32_t rows4[4];
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const uint32_t ow = (uint32_t)__shfl_up((int)word, d, 64), ob = (uint32_t)__shfl_up((int)bits, d, 64);
-                if (lane >= d && ow == word) bits |= ob;
+            for (int g = 0; g < 4; ++g) {
+                const uint64_t p = p0 + (uint64_t)g * 64 + lane;
+                rows4[g] = p < b1 ? post_rows[p] : 0xFFFFFFFFu;
             }
-            const uint32_t nw = (uint32_t)__shfl_down((int)word, 1, 64);
-            if (live && (lane == 63 || nw != word)) atomicOr(&bm[word], bits);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t row = rows4[g];
+                const bool live = row != 0xFFFFFFFFu;
+                const uint32_t word = row >> 5;
+                uint32_t bits = live ? 1u << (row & 31) : 0u;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const uint32_t ow = (uint32_t)__shfl_up((int)word, d, 64), ob = (uint32_t)__shfl_up((int)bits, d, 64);
+                    if (lane >= d && ow == word) bits |= ob;
+                }
+                const uint32_t nw = (uint32_t)__shfl_down((int)word, 1, 64);
+                if (live && (lane == 63 || nw != word)) atomicOr(&bm[word], bits);
+            }
         }
     }
 }
@@ -534,10 +540,11 @@ hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart
 }
 
 hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
-                              const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s)
+                              const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s,
+                              unsigned long long *counter_host)
 {
     hipLaunchKernelGGL(expand_hits_kernel, dim3(1024), dim3(256), 0, s, hits, counter, max_hits, post_rows, bitmaps,
-                       words_per_term);
+                       words_per_term, counter_host);
     return hipGetLastError();
 }
 

@@ -440,6 +440,9 @@ struct I8Rows {
     const float *scale;         // se_r
     const float *rel_err;       // |e - e^| / sqrt(normB), rounded up (0 where normB <= 0)
     const float *rel_hat;       // |e^| / sqrt(normB), rounded up
+    const double *norm_b;       // not null: the epilogue forms the row's scoring constants itself (row_consts_of) from these
+    const int64_t *created;
+    int64_t now_ticks;
 };
 struct I8Queries {
     const int8_t *q1, *q2;      // [B][D]
@@ -450,12 +453,16 @@ struct I8Queries {
 // JR: 16-row groups per unit of work (one wave streams a unit's D columns in stages of eight 16-byte loads per lane:
 // 8/JR k-tiles of JR groups).  8 for the pass over all rows (long sequential streams, few epilogues); 1 for the sampled
 // prefix, whose few thousand rows then spread over hundreds of waves instead of a few dozen (2 x 4096 rows x 3072:
-// 34 -> 6 us, and that launch is on the critical path of a one-query search).
-template <int NQ, bool LOWER, int JR>
+// 34 -> 12 us, and that launch is on the critical path of a one-query search).
+// LISTS (with JR = 1 and floor keys of 0: the sampled prefix): a workgroup's 64 rows per query leave as one sorted list
+// buf[b][64 l .. 64 l + 63], l = unit / 4, what buffer_to_lists would make of them -- no counters, no second launch.
+template <int NQ, bool LOWER, int JR, bool LISTS = false>
 __global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int32_t D, I8Rows R, int64_t n_units, int64_t n_rows,
                                                                 FusedEpilogue epi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lq[];     // [2][NQ][D] int8
+    __shared__ SelEntry own[LISTS ? NQ : 1][kSelWidth];
+    static_assert(!LISTS || JR == 1, "LISTS: one 16-row group per wave");
     constexpr int KS = 8 / JR;                     // k-tiles per stage
     constexpr int UPT = 16 / JR;                   // units per 256-row tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -510,8 +517,14 @@ __global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int
         for (int jj = 0; jj < (JR + 3) / 4; ++jj) {
             if (jj * 4 + sl >= JR) continue;
             const int64_t row = (u / UPT) * kScBN + (u % UPT) * (16 * JR) + 16 * (jj * 4 + sl) + (lane >> 2);
-            if (row >= n_rows) continue;
-            const double2 rc = epi.rowc[row];
+            if (row >= n_rows) {
+                if (LISTS) {
+#pragma unroll
+                    for (int b = 0; b < NQ; ++b) { own[b][wave * 16 + (lane >> 2)].key = 0ull; own[b][wave * 16 + (lane >> 2)].pos = 0xFFFFFFFFu; }
+                }
+                continue;
+            }
+            const double2 rc = R.norm_b ? row_consts_of(R.norm_b[row], R.created[row], R.now_ticks) : epi.rowc[row];
             const double se = (double)R.scale[row], re = (double)R.rel_err[row], rh = (double)R.rel_hat[row];
 #pragma unroll
             for (int b = 0; b < NQ; ++b) {
@@ -530,7 +543,10 @@ __global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int
                 const double sc = fused_score_fast(dot, rc.x, rc.y, mm, qc) + (LOWER ? -err : err);
                 unsigned long long key = score_key(sc);
                 if (!(fabs(sc) <= 1.7976931348623157e308)) key = LOWER ? 1ull : ~0ull;     // non-finite: no floor from it / never dropped
-                if (key > epi.tau[b]) {
+                if (LISTS) {
+                    own[b][wave * 16 + (lane >> 2)].key = key;
+                    own[b][wave * 16 + (lane >> 2)].pos = (uint32_t)row;
+                } else if (key > epi.tau[b]) {
                     const uint32_t slot = atomicAdd(&epi.cnt[b], 1u);
                     if (slot < epi.cap) {
                         SelEntry en;
@@ -539,6 +555,18 @@ __global__ __launch_bounds__(256, 2) void screen_gemv_i8_kernel(I8Queries Q, int
                     }
                 }
             }
+        }
+        if (LISTS) {                               // (n_units is a multiple of 4: a workgroup's waves leave the loop together)
+            __syncthreads();
+            if (wave < NQ) {
+                unsigned long long k = own[wave][lane].key;
+                uint32_t p = own[wave][lane].pos;
+                wave_sort(k, p, lane);
+                SelEntry o;
+                o.key = k; o.pos = p; o.pad = 0;
+                epi.buf[(int64_t)wave * epi.cap + (u / 4) * kSelWidth + lane] = o;
+            }
+            __syncthreads();
         }
     }
 }
@@ -608,8 +636,10 @@ __global__ __launch_bounds__(256) void i8_shadow_kernel(const float *__restrict_
 // Two-level int8 image of up to 8 queries (one workgroup each) and |q - q^|^2.
 __global__ __launch_bounds__(256) void i8_queries_kernel(const float *__restrict__ Qf, int32_t D, int8_t *__restrict__ q1, int8_t *__restrict__ q2,
                                                          float *__restrict__ s1_out, double *__restrict__ err2_out,
-                                                         double *__restrict__ err2_l1_out)
+                                                         double *__restrict__ err2_l1_out, uint32_t *__restrict__ zero, int32_t n_zero)
 {
+    // (the pass's counters, cleared by the first kernel of the call instead of a memset of their own)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < n_zero; i += 256) zero[i] = 0u;
     __shared__ float red_f[4];
     __shared__ double red_d[4], red_d1[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -850,39 +880,43 @@ hipError_t launch_i8_shadow(const float *E, const double *norm_b, int64_t n_rows
 }
 
 // ws: [q1 B*D][q2 B*D] int8, s1 [B] float, err2 [B] double -- see I8Queries.
-hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s, double *err2_level1)
+hipError_t launch_i8_queries(const float *Q, int32_t B, int32_t D, void *q12, float *s1, double *err2, hipStream_t s, double *err2_level1,
+                             uint32_t *zero, int32_t n_zero)
 {
     if (B <= 0) return hipSuccess;
     int8_t *q1 = static_cast<int8_t *>(q12);
-    hipLaunchKernelGGL(i8_queries_kernel, dim3((unsigned)B), dim3(256), 0, s, Q, D, q1, q1 + (size_t)B * D, s1, err2, err2_level1);
+    hipLaunchKernelGGL(i8_queries_kernel, dim3((unsigned)B), dim3(256), 0, s, Q, D, q1, q1 + (size_t)B * D, s1, err2, err2_level1, zero, zero ? n_zero : 0);
     return hipGetLastError();
 }
 
 // The streaming screen over the int8 shadow for up to kMaxGemvScreenQ queries, kMaxI8ScreenQ per launch (two
 // int32 accumulators per query and row).  lower_bound = true: keys are score - bound (prefix floor).
+bool screen_gemv_i8_prefix_makes_lists(int32_t D) { return D % 1024 == 0; }
+
 hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double *err2, int32_t B, const void *tiled,
-                                 const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, int32_t D,
+                                 const float *scale, const float *rel_err, const float *rel_hat, const double *norm_b,
+                                 const int64_t *created, int64_t now_ticks, int64_t n_rows, int32_t D,
                                  const FusedEpilogue &epi, bool lower_bound, hipStream_t s)
 {
     if (B <= 0 || n_rows <= 0) return hipSuccess;
     if (B > kMaxGemvScreenQ || D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
     // the sampled prefix (lower_bound) is a few thousand rows on the critical path of the call: 16-row units spread it over
     // hundreds of waves; the pass over all rows streams 128-row units
-    const bool fine = lower_bound && D % 1024 == 0;
+    const bool fine = lower_bound && screen_gemv_i8_prefix_makes_lists(D);    // sorted lists of 64 into epi.buf (floor keys must be 0)
     const int64_t tiles = (n_rows + kScBN - 1) / kScBN;
     const int64_t n_units = tiles * (fine ? 16 : 2);
     const int64_t blocks = std::min<int64_t>((n_units + 3) / 4, 512);
     const int8_t *q1 = static_cast<const int8_t *>(q12), *q2 = q1 + (size_t)B * D;
-    I8Rows Rd{static_cast<const int8_t *>(tiled), scale, rel_err, rel_hat};
+    I8Rows Rd{static_cast<const int8_t *>(tiled), scale, rel_err, rel_hat, norm_b, created, now_ticks};
     for (int32_t b0 = 0; b0 < B; b0 += kMaxI8ScreenQ) {
         const int32_t nb = std::min<int32_t>(kMaxI8ScreenQ, B - b0);
         const size_t lds = 2 * (size_t)nb * (size_t)D;
         if (lds > 65536) return hipErrorInvalidValue;
         I8Queries Qd{q1 + (size_t)b0 * D, q2 + (size_t)b0 * D, s1 + b0, err2 + b0};
         FusedEpilogue e2 = epi;                              // everything the kernel indexes by query, shifted to b0
-        e2.qc += b0; e2.tau += b0; e2.cnt += b0; e2.buf += (size_t)b0 * epi.cap;
+        e2.qc += b0; e2.tau += b0; if (e2.cnt) e2.cnt += b0; e2.buf += (size_t)b0 * epi.cap;
         if (e2.kw.q_term_off) e2.kw.q_term_off += b0;
-#define ORR_I8(NQ) do { if (fine) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true, 1>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
+#define ORR_I8(NQ) do { if (fine) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true, 1, true>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
                         else if (lower_bound) hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, true, 8>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); \
                         else hipLaunchKernelGGL((screen_gemv_i8_kernel<NQ, false, 8>), dim3((unsigned)blocks), dim3(256), lds, s, Qd, D, Rd, n_units, n_rows, e2); } while (0)
         switch (nb) {
