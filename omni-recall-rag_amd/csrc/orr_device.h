@@ -7,6 +7,20 @@
 
 namespace orr {
 
+// A pointer the compiler has lost track of (it went through an opaque asm, or sits in a struct copied by value inside a
+// persistent loop) is a GENERIC pointer to it: flat_load, which occupies the LDS path as well, counts on both waitcnt
+// counters and takes a 64-bit address per lane.  Saying where it points restores global_load with a scalar base.
+template <typename T> using gptr = const __attribute__((address_space(1))) T *;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(const T *p) { return (gptr<T>)p; }
+// (HIP's float4 / double2 classes have no constructor from an address-space-qualified object: loads go through the
+// native vector types of the same layout)
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+typedef double gf64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 load_global(const float4 *p, uint32_t i) { const gf32x4 v = as_global(reinterpret_cast<const gf32x4 *>(p))[i]; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float2 load_global(const float2 *p, uint32_t i) { const gf32x2 v = as_global(reinterpret_cast<const gf32x2 *>(p))[i]; return make_float2(v.x, v.y); }
+__device__ __forceinline__ double2 load_global(const double2 *p, uint32_t i) { const gf64x2 v = as_global(reinterpret_cast<const gf64x2 *>(p))[i]; double2 r; r.x = v.x; r.y = v.y; return r; }
+
 // ---------------------------------------------------------------------------
 // score <-> sortable key.  Larger key = ranks earlier.  double.CompareTo puts
 // NaN below every number and treats -0 == +0.

@@ -50,25 +50,41 @@ struct EpiTileLoads {
     uint32_t w[NI][NJ][kCountPlanes];
 };
 
+// (Addresses: every load is a wave-uniform base -- the plane of (p, query group), the constants' arrays -- plus the lane's
+// row as a 32-bit offset, so the base stays in scalar registers and no lane computes a 64-bit address: with the lanes
+// doing that for each of the 18 loads per row tile the requests alone were 3,500 cycles of a one-wave SIMD.  Rows per
+// launch < 2^28: the callers' shards are far below.)
 template <int NI, int NJ>
 __device__ __forceinline__ void epilogue_issue_loads(EpiTileLoads<NI, NJ> &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                      const FusedEpilogue &epi, int lane)
 {
     const int fr = lane & 31;
     const int32_t n_qg = (B + 31) >> 5;
+    // No branch in here: an absent array (no int8 row constants: the bf16 kernels; no count words: a batch without query
+    // terms) is replaced by the rows' constants as a readable stand-in and its values by their defaults afterwards.  (As
+    // "pointer ? load : default" the compiler built a branch around each load with an s_waitcnt vmcnt(0) inside: the
+    // tile's loads went out one row tile at a time, 8,000-10,000 cycles per output tile by the stamps.)
+    const bool has_rf = epi.i8_rowf != nullptr, has_cp = epi.count_planes != nullptr;
+    const float4 *rowf = has_rf ? epi.i8_rowf : reinterpret_cast<const float4 *>(epi.rowc);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int64_t col = colbase + j * 32 + fr;
-        const int64_t colc = col < n_rows ? col : n_rows - 1;              // clamped, never branched around
-        L.rc[j] = epi.rowc[colc];
-        L.rf[j] = epi.i8_rowf ? epi.i8_rowf[colc] : make_float4(1.f, 0.f, 0.f, 0.f);
+        const uint32_t colc = (uint32_t)(col < n_rows ? col : n_rows - 1);     // clamped, never branched around
+        L.rc[j] = load_global(epi.rowc, colc);
+        const float4 rf = load_global(rowf, colc);
+        L.rf[j] = has_rf ? rf : make_float4(1.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int qg = (qbase + i * 32) >> 5;
             const int qgc = qg < n_qg ? qg : n_qg - 1;
 #pragma unroll
-            for (int p = 0; p < kCountPlanes; ++p)
-                L.w[i][j][p] = epi.count_planes ? epi.count_planes[((int64_t)p * n_qg + qgc) * epi.plane_stride + colc] : 0u;
+            for (int p = 0; p < kCountPlanes; ++p) {
+                // wave-uniform base (the plane of (p, query group)) + the lane's row
+                const gptr<uint32_t> plane = as_global(has_cp ? epi.count_planes + ((int64_t)p * n_qg + qgc) * epi.plane_stride
+                                                              : reinterpret_cast<const uint32_t *>(epi.rowc));
+                const uint32_t wv = plane[colc];
+                L.w[i][j][p] = has_cp ? wv : 0u;
+            }
         }
     }
 }
@@ -82,11 +98,33 @@ __device__ __forceinline__ void epilogue_issue_loads(EpiTileLoads<NI, NJ> &L, in
 //
 // pre / qf_lds (STAGED): the caller's pre-issued loads and the tile's query constants in LDS, indexed by
 // [query - qbase]; otherwise (orr_gemm.hip) everything is loaded here and only pass 1b runs.
-template <int NI, int NJ, bool RESCORED, typename ACC = f32x16, bool STAGED = false, int QDEPTH = kEpiQueue>
+// AGPR: the caller's accumulators live in accumulation registers (a wave with 256 of them); each element is then taken
+// out with an explicit v_accvgpr_read where it is used -- left to itself the register allocator parks all 256 in
+// scratch memory behind the K loop and reads them back one by one.
+template <bool AGPR, typename T>
+__device__ __forceinline__ float acc_as_float(T v)
+{
+    if constexpr (AGPR) {
+        T r;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(v));
+        return (float)r;
+    } else {
+        return (float)v;
+    }
+}
+
+struct EpiNoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// between_blocks(i): called once per block of 32 queries, in front of it (the 4-wave screening kernel spreads the requests
+// that refill its operand rings over the epilogue this way: issued in one piece they were 3,000 cycles of a CU's address
+// path with nothing else going on).
+template <int NI, int NJ, bool RESCORED, typename ACC = f32x16, bool STAGED = false, int QDEPTH = kEpiQueue, bool AGPR = false,
+          typename HOOK = EpiNoHook>
 __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qbase, int64_t colbase, int32_t B,
                                                int64_t n_rows, const FusedEpilogue &epi, int lane, EpiParked *queue,
                                                int queue_stride, uint32_t idx_salt = 0, unsigned long long *st = nullptr,
-                                               const EpiTileLoads<NI, NJ> *pre = nullptr, const float4 *qf_lds = nullptr)
+                                               const EpiTileLoads<NI, NJ> *pre = nullptr, const float4 *qf_lds = nullptr,
+                                               HOOK between_blocks = HOOK())
 {
     constexpr bool INT_ACC = !__is_same(ACC, f32x16);
     // st (diagnostic, ORR_SCREEN_STAMPS): s_memtime of lane 0 at the phases of this call -- [4] row constants in registers,
@@ -125,6 +163,7 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
     };
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+        between_blocks(i);
         // Count words (four bits per query, word k = queries 8 k .. 8 k + 7 of the block) shifted so that element e's query
         // sits at the COMPILE-TIME nibble e & 3 of word e >> 2: the count is one v_bfe with immediates.
         uint32_t w[NJ][kCountPlanes];
@@ -138,22 +177,26 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
             // the bound and one compare per element: a row past the end has cj = -inf (its bound is below every floor) and a
             // query past the batch was staged with a floor of +inf.
             unsigned long long wave_any = 0ull;
+            // the constants of four queries are requested together and ONE GROUP AHEAD of their use (left to itself the
+            // compiler issues each LDS read right in front of its use; with one wave on the SIMD nobody covers that trip)
+            float4 qfg[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qfg[0][e] = qf_of(i, e);
 #pragma unroll
             for (int e0 = 0; e0 < 16; e0 += 4) {
-                // four queries' constants requested together: left to itself the compiler issues each LDS read right in front
-                // of its use (registers are short), one exposed LDS trip per element
-                float4 qf8[4];
+                if (e0 + 4 < 16) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) qf8[e] = qf_of(i, e0 + e);
+                    for (int e = 0; e < 4; ++e) qfg[((e0 >> 2) + 1) & 1][e] = qf_of(i, e0 + 4 + e);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e1 = 0; e1 < 4; ++e1) {
                     const int e = e0 + e1;
-                    const float4 qf = qf8[e1];
+                    const float4 qf = qfg[(e0 >> 2) & 1][e1];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
-                        const float a = (float)acc[i][j][e];
+                        const float a = acc_as_float<AGPR>(acc[i][j][e]);
                         const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
                         wave_any |= __builtin_amdgcn_ballot_w64(!(upper < qf.y));      // NaN bounds (float accumulators that overflowed) are kept
                     }
@@ -175,7 +218,7 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
-                const float a = (float)acc[i][j][e];                       // int8 GEMM: |I| <= 3072 * 127^2, the conversion costs at most 2^-24
+                const float a = acc_as_float<AGPR>(acc[i][j][e]);          // int8 GEMM: |I| <= 3072 * 127^2, the conversion costs at most 2^-24
                 // score bound: a (qf.x rb) + recency + keyword credit + (int8) the pair's quantisation bound
                 const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
                 // NaN and overflowed sums (float accumulators only) are never dropped here

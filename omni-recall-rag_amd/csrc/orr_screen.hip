@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
         float2 qf_part;
         {
             const int q = b0 + (tid >> 1);
-            qf_part = reinterpret_cast<const float2 *>(ep.qf + (q < B ? q : B - 1))[tid & 1];
+            qf_part = load_global(reinterpret_cast<const float2 *>(ep.qf), (uint32_t)(2 * (q < B ? q : B - 1) + (tid & 1)));
             if (q >= B) qf_part = (tid & 1) ? make_float2(0.f, 0.f) : make_float2(0.f, __builtin_huge_valf());   // no query: {0, floor +inf, 0, 0}
         }
         EpiTileLoads<LI, 2> pre;
@@ -324,6 +324,290 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
     ++tile_seq;
     ring_a = (ring_a + T) % kScNA;
     ring_b = (ring_b + T) % kScNB;
+    id = next_id;
+    }
+#undef ORR_STAMP
+}
+
+// ---------------------------------------------------------------------------
+// The same tile with FOUR waves, one per SIMD (screen_tile4_kernel).  LIVE = 8: waves as 2 x 2, each 128 queries x 128
+// rows = 4 x 4 accumulator tiles (256 accumulator registers); LIVE <= 4: 1 x 4, each (32 LIVE) x 64.  Per K-tile and
+// wave 32 MFMAs (1,024 cycles) against 16 fragment reads and 8 requests, all of it one instruction stream with nobody to
+// share the SIMD with: the fragment reads of the NEXT half K-tile and the requests go out between the MFMAs of the
+// current one, and the one barrier per K-tile sits between the two halves (by then every wave has read the tile's
+// second half, so its stage is free, and the next tile has landed).  Fragments are double-buffered per HALF K-tile
+// (64 registers), the rings are 3 query + 6 row stages, the epilogue keeps 16 KiB.
+// ---------------------------------------------------------------------------
+constexpr int kS4NA = 3, kS4NB = 6;
+constexpr int kS4Queue = 6;
+constexpr int kS4EpiBytes = kS4Queue * 8 * 256 + 4096;
+constexpr int kS4Lds = (kS4NA + kS4NB) * kScImage + kS4EpiBytes;
+static_assert(kS4Lds <= 160 * 1024, "the rings and the epilogue's region must fit a CU's LDS");
+
+template <bool FUSED, bool I8, int LIVE = 8, bool NT = false>
+__global__ __launch_bounds__(256, 1) void screen_tile4_kernel(const __bf16 *__restrict__ Qh, int32_t B,
+                                                              const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
+                                                              int32_t D, float *__restrict__ S, int64_t s_stride,
+                                                              int32_t n_ntiles, int32_t n_mtiles, int32_t flags, FusedEpilogue epi)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const lds_a = lds, *const lds_b = lds + kS4NA * kScImage, *const lds_epi = lds + (kS4NA + kS4NB) * kScImage;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NI = LIVE >= 4 ? 4 : LIVE;                               // query tiles of a wave
+    constexpr int NJ = LIVE == 8 ? 4 : 2;                                  // row tiles of a wave
+    const int wr = LIVE == 8 ? wave >> 1 : 0, wc = LIVE == 8 ? wave & 1 : wave;
+    const bool row_loader = wave >= 2;                                      // waves 2, 3 request rows, waves 0, 1 queries
+    constexpr int kPA = LIVE == 8 ? 8 : LIVE == 4 ? 4 : 2;                  // query pieces per K-tile and requesting wave
+    constexpr int kPB = 8;                                                  // row pieces per K-tile and requesting wave
+    const int total_ids = ((n_ntiles + 7) / 8) * 8 * n_mtiles;              // (walk of the output tiles: as in screen_bf16_kernel)
+    auto valid_from = [&](int id) {
+        while (id < total_ids && ((id >> 3) / n_mtiles) * 8 + (id & 7) >= n_ntiles) id += gridDim.x;
+        return id;
+    };
+    const int T = I8 ? D / 64 : D / kScBK;
+    const int fr = lane & 31, fh = lane >> 5;
+    const uint32_t lane_off = (uint32_t)(lane * 16);
+    const uint32_t part_off = row_loader ? (uint32_t)((wave & 1) * kPB * 1024) : (uint32_t)(wave * kPA * 1024);
+    auto stream_src = [&](int sid) -> const unsigned char * {
+        const int smt = (sid >> 3) % n_mtiles, snt = ((sid >> 3) / n_mtiles) * 8 + (sid & 7);
+        return row_loader ? reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + snt) * T) * kScImage + part_off
+                          : reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)smt * T) * kScImage + part_off;
+    };
+    int s_id = valid_from(blockIdx.x), s_k = 0, s_stage = 0;
+    const unsigned char *s_src = s_id < total_ids ? stream_src(s_id) : nullptr;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(row_loader ? lds_b : lds_a) + part_off;
+    const int ring_n = row_loader ? kS4NB : kS4NA;
+    // NT: the rows are streamed once (the whole batch fits one query tile): requested non-temporal, so they do not push the
+    // query images (re-read by every workgroup) out of L2.  (A template parameter, and the piece index a constant at every
+    // call, and the K loop below exists once per role: a request is M0, a wait state and the load, no branch.)
+    auto issue_piece = [&](auto role, int slot) __attribute__((always_inline)) {
+        constexpr bool ROWS = decltype(role)::value;
+        if constexpr (!ROWS && kPA < kPB) { if (slot >= kPA) return; }
+        // (the immediate offset, applied to both addresses, has 12 bits: pieces 4..7 go through bases 4 KiB further on)
+        const uint32_t m0v = ring_lds + (uint32_t)s_stage * kScImage + (uint32_t)(slot >> 2) * 4096u;
+        const uint64_t src = (uint64_t)(uintptr_t)s_src + (uint64_t)(slot >> 2) * 4096u;
+#define ORR_GLDS(OFF, POLICY) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF POLICY \
+                                           :: "v"(lane_off), "s"(src), "s"(m0v) : "memory")
+        if constexpr (NT && ROWS) {
+            switch (slot & 3) { case 0: ORR_GLDS(0, " nt"); break; case 1: ORR_GLDS(1024, " nt"); break; case 2: ORR_GLDS(2048, " nt"); break; default: ORR_GLDS(3072, " nt"); }
+        } else {
+            switch (slot & 3) { case 0: ORR_GLDS(0, ""); break; case 1: ORR_GLDS(1024, ""); break; case 2: ORR_GLDS(2048, ""); break; default: ORR_GLDS(3072, ""); }
+        }
+#undef ORR_GLDS
+    };
+    auto advance_stream = [&]() {
+        s_stage = s_stage + 1 == ring_n ? 0 : s_stage + 1;
+        if (s_k + 1 < T) { ++s_k; s_src += kScImage; return; }
+        const int nid = valid_from(s_id + gridDim.x);
+        if (nid < total_ids) { s_id = nid; s_k = 0; s_src = stream_src(nid); }
+    };
+    int ring_a = 0, ring_b = 0;
+    bool first = true;
+    int tile_seq = 0;
+#define ORR_STAMP(k) if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + (k)] = __builtin_amdgcn_s_memtime()
+    for (int id = valid_from(blockIdx.x); id < total_ids;) {
+    ORR_STAMP(0);
+    const int next_id = valid_from(id + gridDim.x);
+    const bool has_next = next_id < total_ids;
+    const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
+    const int64_t n0 = row_first + (int64_t)nt * kScBN;
+    const int b0 = mt * kScBM;
+
+    typename std::conditional<I8, i32x16v, f32x16>::type acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+    struct Frag { bf16x8 a[NI], b[NJ]; };
+    int c_a = ring_a, c_b = ring_b;                                         // ring stages of the K-tile whose fragments are read next
+    // fragment addresses: row = tile row + (lane & 31), 16-byte slot = chunk ^ ((row >> 2) & 3) with chunk = 2 ks + (lane >> 5);
+    // ks = 1 flips bit 5 of the address (one wave per SIMD has the registers to keep both)
+    const int frag0 = (lane & 31) * 64 + (((lane >> 5) ^ ((lane >> 2) & 3)) << 4), frag1 = frag0 ^ 32;
+    auto a_at = [&](int ks) { return lds_a + c_a * kScImage + wr * 128 * 64 + (ks ? frag1 : frag0); };
+    auto b_at = [&](int ks) { return lds_b + c_b * kScImage + wc * (NJ * 32) * 64 + (ks ? frag1 : frag0); };
+    auto next_stage = [&]() { c_a = c_a + 1 == kS4NA ? 0 : c_a + 1; c_b = c_b + 1 == kS4NB ? 0 : c_b + 1; };
+
+    // One instruction stream per SIMD: a 32 x 32 x 32 MFMA holds the matrix pipe for 32 cycles, and whatever the wave issues
+    // behind it in that time is free.  So the stream is 32 slots per K-tile, each one MFMA followed by AT MOST one fragment
+    // read and one request -- nothing is issued in clumps (with the reads and requests grouped after every four MFMAs the
+    // K-tile took 1,940 cycles for 1,024 of MFMA).
+#define ORR_SB __builtin_amdgcn_sched_barrier(0)
+#define ORR_MM(f, i, j) \
+    if constexpr ((i) < NI && (j) < NJ) { \
+        if constexpr (I8) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4v, f.a[i]), __builtin_bit_cast(i32x4v, f.b[j]), acc[i][j], 0, 0, 0); \
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0); } ORR_SB
+#define ORR_RA(f, p, i) if constexpr ((i) < NI) f.a[i] = *reinterpret_cast<const bf16x8 *>((p) + (i) * 2048); ORR_SB
+#define ORR_RB(f, p, j) if constexpr ((j) < NJ) f.b[j] = *reinterpret_cast<const bf16x8 *>((p) + (j) * 2048); ORR_SB
+    // The epilogue's one trip to global memory (this thread's query constants for the LDS copy, its rows' constants and
+    // count words, orr_epilogue.h) is requested from INSIDE the K loop, behind the barrier of the last K-tile but one:
+    // a wave's loads return in order, so behind the requests of the next output tile's first K-tiles they would arrive
+    // when that whole ring has (10,000 cycles per tile by the stamps).  Hence also: the last kS4NA / kS4NB iterations
+    // request nothing (their counted waits shrink with what is left in flight), and the ring is refilled for the next
+    // output tile only when the epilogue's inputs are in registers -- it fills while the epilogue computes.
+    FusedEpilogue ep = epi;
+    EpiTileLoads<NI, NJ> pre;
+    float4 qf_mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto epilogue_requests = [&]() __attribute__((always_inline)) {
+        if constexpr (FUSED) {
+            // laundered once per output tile: otherwise everything derived from these is hoisted out of the persistent loop
+            asm volatile("" : "+s"(ep.rowc), "+s"(ep.qc), "+s"(ep.tau), "+s"(ep.qf), "+s"(ep.count_planes), "+s"(ep.plane_stride),
+                              "+s"(ep.i8_rowf), "+s"(ep.i8_qs1), "+s"(ep.cnt), "+s"(ep.buf));
+            asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
+            const int q = b0 + tid;
+            qf_mine = load_global(ep.qf, (uint32_t)(q < B ? q : B - 1));
+            epilogue_issue_loads(pre, b0 + wr * 128, n0 + wc * (NJ * 32), B, n_rows, ep, lane);
+        }
+    };
+    auto refill = [&](auto role) __attribute__((always_inline)) {          // every stage of this wave's ring requested
+        for (int t = 0; t < ring_n; ++t) {
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) issue_piece(role, sl);
+            advance_stream();
+        }
+    };
+    // (one copy of the loop per requesting role: the counted waits and the request policy are then immediates)
+    auto k_loop = [&](auto role) __attribute__((always_inline)) {
+    constexpr bool ROWS = decltype(role)::value;
+    constexpr int RING = ROWS ? kS4NB : kS4NA, KP = ROWS ? kPB : kPA;
+    if (first) refill(role);
+    first = false;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(KP * (RING - 1)) : "memory");     // tile 0 awaited by its requesters, then visible to everybody
+    Frag f0, f1;
+    {
+        const unsigned char *pa = a_at(0), *pb = b_at(0);
+        ORR_RA(f0, pa, 0); ORR_RA(f0, pa, 1); ORR_RA(f0, pa, 2); ORR_RA(f0, pa, 3);
+        ORR_RB(f0, pb, 0); ORR_RB(f0, pb, 1); ORR_RB(f0, pb, 2); ORR_RB(f0, pb, 3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // one K-tile.  REQ: its stages are re-requested (K-tile t + RING of this output tile); WAITN: what may stay in flight
+    // when this wave's pieces of K-tile t + 1 have landed; HOOK: the epilogue's requests go out behind the barrier
+    auto tile_iter = [&](auto req_c, auto waitn_c, auto hook_c) __attribute__((always_inline)) {
+        constexpr bool REQ = decltype(req_c)::value, HOOK = decltype(hook_c)::value;
+        constexpr int WAITN = decltype(waitn_c)::value;
+        // first half: tile t, first half of its k from f0; the reads of the second half go out behind the first MFMAs
+        const unsigned char *pa = a_at(1), *pb = b_at(1);
+        ORR_SB;
+        ORR_MM(f0, 0, 0); ORR_RA(f1, pa, 0);
+        ORR_MM(f0, 0, 1); ORR_RA(f1, pa, 1);
+        ORR_MM(f0, 0, 2); ORR_RA(f1, pa, 2);
+        ORR_MM(f0, 0, 3); ORR_RA(f1, pa, 3);
+        ORR_MM(f0, 1, 0); ORR_RB(f1, pb, 0);
+        ORR_MM(f0, 1, 1); ORR_RB(f1, pb, 1);
+        ORR_MM(f0, 1, 2); ORR_RB(f1, pb, 2);
+        ORR_MM(f0, 1, 3); ORR_RB(f1, pb, 3);
+        ORR_MM(f0, 2, 0); ORR_MM(f0, 2, 1); ORR_MM(f0, 2, 2); ORR_MM(f0, 2, 3);
+        ORR_MM(f0, 3, 0); ORR_MM(f0, 3, 1); ORR_MM(f0, 3, 2); ORR_MM(f0, 3, 3);
+        // every wave has read tile t completely and this wave's pieces of tile t + 1 have landed: after the barrier tile
+        // t + 1 is readable and tile t's stages are free
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(WAITN) : "memory");
+        ORR_SB;
+        next_stage();
+        pa = a_at(0); pb = b_at(0);
+        if constexpr (HOOK) epilogue_requests();
+        ORR_SB;
+#define ORR_P(k) if constexpr (REQ) { issue_piece(role, k); } ORR_SB
+        ORR_MM(f1, 0, 0); ORR_RA(f0, pa, 0); ORR_P(0);
+        ORR_MM(f1, 0, 1); ORR_RA(f0, pa, 1);
+        ORR_MM(f1, 0, 2); ORR_RA(f0, pa, 2); ORR_P(1);
+        ORR_MM(f1, 0, 3); ORR_RA(f0, pa, 3);
+        ORR_MM(f1, 1, 0); ORR_RB(f0, pb, 0); ORR_P(2);
+        ORR_MM(f1, 1, 1); ORR_RB(f0, pb, 1);
+        ORR_MM(f1, 1, 2); ORR_RB(f0, pb, 2); ORR_P(3);
+        ORR_MM(f1, 1, 3); ORR_RB(f0, pb, 3);
+        ORR_MM(f1, 2, 0); ORR_P(4);
+        ORR_MM(f1, 2, 1);
+        ORR_MM(f1, 2, 2); ORR_P(5);
+        ORR_MM(f1, 2, 3);
+        ORR_MM(f1, 3, 0); ORR_P(6);
+        ORR_MM(f1, 3, 1);
+        ORR_MM(f1, 3, 2); ORR_P(7);
+        ORR_MM(f1, 3, 3);
+#undef ORR_P
+        if constexpr (REQ) advance_stream();
+        ORR_SB;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int t = 0; t < T - RING; ++t)
+        tile_iter(std::true_type{}, std::integral_constant<int, KP * (RING - 2)>{}, std::false_type{});
+    ORR_STAMP(7);
+    // the last RING K-tiles: r-th of them leaves RING - 2 - r tiles in flight (the last one waits for nothing: 63)
+    auto tail = [&](auto self, auto r_c) __attribute__((always_inline)) {
+        constexpr int r = decltype(r_c)::value;
+        if constexpr (r < RING) {
+            tile_iter(std::false_type{}, std::integral_constant<int, (r <= RING - 2 ? KP * (RING - 2 - r) : 63)>{},
+                      std::integral_constant<bool, r == RING - 2>{});
+            self(self, std::integral_constant<int, r + 1>{});
+        }
+    };
+    tail(tail, std::integral_constant<int, 0>{});
+    };
+    if (row_loader) k_loop(std::true_type{}); else k_loop(std::false_type{});
+    ORR_STAMP(1);
+
+    if (!FUSED) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int64_t col = n0 + wc * (NJ * 32) + j * 32 + fr;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = b0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
+                }
+            }
+        if (has_next) { if (row_loader) refill(std::true_type{}); else refill(std::false_type{}); }
+    } else {
+        uint32_t salt = 0;
+        asm volatile("" : "+s"(salt));
+        if (b0 + tid >= B) qf_mine = make_float4(0.f, __builtin_huge_valf(), 0.f, 0.f);    // no query: floor +inf
+        EpiParked *queue = reinterpret_cast<EpiParked *>(lds_epi) + tid;
+        float4 *qf_lds = reinterpret_cast<float4 *>(lds_epi + kS4Queue * 8 * 256);
+        qf_lds[tid] = qf_mine;
+        // every loaded register is touched here: the compiler's wait for the loads lands HERE, in front of the refill (further
+        // down it would wait for the refill's requests as well, which are younger)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            asm volatile("" : "+v"(pre.rc[j].x), "+v"(pre.rc[j].y));
+            asm volatile("" : "+v"(pre.rf[j].x), "+v"(pre.rf[j].y), "+v"(pre.rf[j].z), "+v"(pre.rf[j].w));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int pl = 0; pl < kCountPlanes; ++pl) asm volatile("" : "+v"(pre.w[i][j][pl]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (bare: __syncthreads() would also wait for outstanding requests)
+        unsigned long long *st = (epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
+        // the ring refill for the next output tile rides on the epilogue: a quarter of this wave's requests in front of each
+        // block of 32 queries (NI blocks; the last one takes what is left)
+        auto refill_part = [&](int blk) __attribute__((always_inline)) {
+            if (!has_next) return;
+            auto part = [&](auto role) __attribute__((always_inline)) {
+                constexpr int RING = decltype(role)::value ? kS4NB : kS4NA;
+                const int t0 = blk * RING / NI, t1 = blk + 1 == NI ? RING : (blk + 1) * RING / NI;
+                for (int t = t0; t < t1; ++t) {
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) issue_piece(role, sl);
+                    advance_stream();
+                }
+            };
+            if (row_loader) part(std::true_type{}); else part(std::false_type{});
+        };
+        fused_epilogue<NI, NJ, true, typename std::conditional<I8, i32x16v, f32x16>::type, true, kS4Queue, LIVE == 8>(
+            acc, b0 + wr * 128, n0 + wc * (NJ * 32), B, n_rows, ep, lane, queue, 256, salt, st, &pre, qf_lds + wr * 128, refill_part);
+    }
+#undef ORR_RB
+#undef ORR_RA
+#undef ORR_MM
+#undef ORR_SB
+    ORR_STAMP(2);
+    if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    ++tile_seq;
+    ring_a = (ring_a + T) % kS4NA;
+    ring_b = (ring_b + T) % kS4NB;
     id = next_id;
     }
 #undef ORR_STAMP
@@ -822,10 +1106,26 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
         hipLaunchKernelGGL((screen_bf16_kernel<true, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
-    if (B > 128) ORR_LAUNCH_I8(8);
+#define ORR_LAUNCH_I8W4(L, NT) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_tile4_kernel<true, true, L, NT>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kS4Lds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_tile4_kernel<true, true, L, NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
+    // From 65 queries up (two or more live 32-query tiles per wave... the matrix cores carry the launch) the four-wave form
+    // of the tile; below, the eight-wave form (HBM-bound there, and its two waves per SIMD hide the epilogue's latencies).
+    // Measured, 1M x 3072 rows: 128 queries 0.756 -> 0.619 ms, 256: 0.862 -> 0.842, 1024: 3.42 -> 3.30; 64: 0.485 vs 0.506.
+    if (B > 64 && D / 64 >= kS4NB) {
+        if (B > 256) ORR_LAUNCH_I8W4(8, false);
+        else if (B > 128) ORR_LAUNCH_I8W4(8, true);
+        else ORR_LAUNCH_I8W4(4, true);
+    }
+    else if (B > 128) ORR_LAUNCH_I8(8);
     else if (B > 64) ORR_LAUNCH_I8(4);
     else if (B > 32) ORR_LAUNCH_I8(2);
     else ORR_LAUNCH_I8(1);
+#undef ORR_LAUNCH_I8W4
 #undef ORR_LAUNCH_I8
     if (stamp_path) {
         std::vector<unsigned long long> h(kStampWords);

@@ -38,6 +38,10 @@ if v2.any():
                        ("blocks 2..4", e5, e6), ("pass 2 + tail", e6, s2)):
         d = (b - a)[v2]
         print("  %-36s median %6d  p90 %6d" % (name, np.median(d), np.percentile(d, 90)))
+s7 = launch[..., 7].astype(np.int64)
+v7 = valid & (s7 > 0)
+if v7.any():
+    print("K loop: start -> tail %d, tail -> end %d (medians)" % (np.median((s7 - s0)[v7]), np.median((s1 - s7)[v7])))
 # the first tile of a workgroup includes the cold prologue
 seq_k = [(s1 - s0)[:, t][valid[:, t]] for t in range(min(6, valid.shape[1]))]
 print("K loop by tile sequence:", [int(np.median(x)) for x in seq_k if x.size])

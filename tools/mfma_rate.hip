@@ -1,0 +1,98 @@
+// mfma_rate.hip -- what one wave per SIMD can issue: v_mfma_i32_32x32x32_i8 back to back (16 independent accumulator tiles,
+// the screening kernel's shape), alone or with one ds_read_b128 behind each, on every CU at once.  Prints cycles per MFMA
+// (s_memtime) and the clock (s_memtime / s_memrealtime).  Diagnostic for DESIGN.md's K-loop bound; not part of the library.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void rate_kernel(int iters, unsigned long long *out, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) reinterpret_cast<int *>(lds)[i] = i * 2654435761u;
+    __syncthreads();
+    i32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    i32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = *reinterpret_cast<const i32x4 *>(lds + lane * 16 + i * 2048); b[i] = *reinterpret_cast<const i32x4 *>(lds + 8192 + lane * 16 + i * 2048); }
+    const unsigned char *p = lds + lane * 16;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE == 1 && j < 2) {               // 8 reads per 16 MFMAs, as the kernel's half K-tile
+                    if (j == 0) a[i] = *reinterpret_cast<const i32x4 *>(p + ((it + i) & 7) * 2048);
+                    else b[i] = *reinterpret_cast<const i32x4 *>(p + 16384 + ((it + i) & 7) * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 0x12345678) *sink = s;
+    if (lane == 0) {
+        const int w = blockIdx.x * WAVES + (threadIdx.x >> 6);
+        out[2 * w] = t1 - t0;
+        out[2 * w + 1] = r1 - r0;
+    }
+}
+
+template <int MODE, int WAVES>
+static void run(const char *what, int blocks, int iters)
+{
+    unsigned long long *d = nullptr;
+    int *sink = nullptr;
+    hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long) * 2 * blocks * WAVES);
+    hipMalloc(reinterpret_cast<void **>(&sink), 4);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(rate_kernel<MODE, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((rate_kernel<MODE, WAVES>), dim3(blocks), dim3(WAVES * 64), 160 * 1024, 0, iters, d, sink);
+        hipDeviceSynchronize();
+    }
+    std::vector<unsigned long long> h(2 * blocks * WAVES);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> cyc, clk;
+    for (int w = 0; w < blocks * WAVES; ++w) { cyc.push_back((double)h[2 * w] / (16.0 * iters)); clk.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 100e6); }
+    std::sort(cyc.begin(), cyc.end());
+    std::sort(clk.begin(), clk.end());
+    printf("%-44s %d wave(s)/SIMD x %d workgroups: %.1f cycles per MFMA per wave (median), clock %.2f GHz\n", what, WAVES / 4, blocks,
+           cyc[cyc.size() / 2], clk[clk.size() / 2] / 1e9);
+    hipFree(d);
+    hipFree(sink);
+}
+
+int main()
+{
+    int cus = 0;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    const int iters = 20000;          // 320k MFMAs per wave: ~5 ms
+    run<0, 4>("MFMA only", 1, iters);
+    run<0, 4>("MFMA only", cus, iters);
+    run<1, 4>("MFMA + one ds_read_b128 behind half of them", cus, iters);
+    run<0, 8>("MFMA only", cus, iters);
+    run<1, 8>("MFMA + one ds_read_b128 behind half of them", cus, iters);
+    return 0;
+}
