@@ -189,6 +189,9 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
                     for (int e = 0; e < 4; ++e) qfg[((e0 >> 2) + 1) & 1][e] = qf_of(i, e0 + 4 + e);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // (the answers of a group are collected first and OR-ed afterwards: OR-ed one by one, every scalar OR waits for the
+                // vector compare in front of it, and one wave has nobody to fill those waits)
+                unsigned long long hit[4][NJ];
 #pragma unroll
                 for (int e1 = 0; e1 < 4; ++e1) {
                     const int e = e0 + e1;
@@ -198,9 +201,13 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
                         const uint32_t m = (w[j][e >> 2] >> (4 * (e & 3))) & 15u;
                         const float a = acc_as_float<AGPR>(acc[i][j][e]);
                         const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
-                        wave_any |= __builtin_amdgcn_ballot_w64(!(upper < qf.y));      // NaN bounds (float accumulators that overflowed) are kept
+                        hit[e1][j] = __builtin_amdgcn_ballot_w64(!(upper < qf.y));      // NaN bounds (float accumulators that overflowed) are kept
                     }
                 }
+#pragma unroll
+                for (int e1 = 0; e1 < 4; ++e1)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) wave_any |= hit[e1][j];
             }
             if (wave_any == 0ull) {
                 if (i == 0) { ORR_EPI_STAMP(5); }
