@@ -1852,7 +1852,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                     1.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, n, idx->dim, epi, s));
                 } else if (ts_i8) {
-                    Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 12.0 * (double)n + 2.0 * (double)B * idx->dim);
+                    Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 28.0 * (double)n + 2.0 * (double)B * idx->dim);   // per row: scale, two relative norms (12 B), normB and created (16 B)
                     HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
                                                        idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(),
                                                        idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->dim, epi, false, s));
