@@ -1,3 +1,2 @@
 mkdir -p gpurun_out/r2
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2/t_all.log 2>&1; tail -3 gpurun_out/r2/t_all.log
-bash tools/profile_round.sh > gpurun_out/r2/profile_round.log 2>&1; tail -25 gpurun_out/r2/profile_round.log
+bash tools/bench_sweep.sh > gpurun_out/r2/sweep.log 2>&1; tail -22 gpurun_out/r2/sweep.log
