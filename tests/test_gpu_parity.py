@@ -813,3 +813,60 @@ def test_keyword_hit_list_overflow_grows_the_list_and_repeats_the_pass():
     rows2, scores2, _ = idx.search(qs, terms, NOW, 10, candidate_limit=n)
     assert idx.search_stats()["passes"] == 1 and np.array_equal(rows2, rows) and np.array_equal(scores2, scores)
     idx.close()
+
+
+def test_four_wave_screening_kernel_variants_match_oracle():
+    """From 65 queries up and 6+ K-tiles (dim >= 384) the int8 screening GEMM runs in its four-wave form
+    (screen_tile4_kernel): 65..128 queries as 1 x 4 waves, 129..256 as 2 x 2 with the rows requested non-temporal, more than
+    256 with several query tiles per row tile.  Row count not a multiple of the 256-row tile, batch sizes that are not
+    multiples of 32, rows that quantise badly (they must survive the screen), a zero query, duplicates of a row
+    (ties at the cut), queries with and without terms -- each batch against the oracle, bit for bit."""
+    P = pkg()
+    rng = np.random.default_rng(4242)
+    n, dim = 200_019, 512                                                # 8 K-tiles; the last row tile holds 83 rows
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    emb[1000:1040, 3] = np.float32(500.0)                                # one coordinate dominates the scale
+    emb[2000:2040] = 0.0
+    emb[3000:3040] *= np.float32(1e25)
+    emb[n - 83:n - 60] = emb[5]                                          # duplicates inside the partial tile
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "rollout"])
+    contents = [" ".join(w).encode() for w in words[rng.integers(0, len(words), (n, 4))]]
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], contents[r0:r0 + 50_000])
+    idx.seal()
+    B = 300
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    qs[0] = emb[5]
+    qs[1] = emb[1010] * np.float32(0.01)
+    qs[2] = 0.0
+    qs[3] = emb[3005]
+    qs[64] = emb[n - 1]
+    qs[129] = emb[77_777] * np.float32(3.0)
+    qs[257] = emb[n - 70]
+    qs[299] = emb[123]
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] if b % 3 else "" for b in range(B)]
+    terms = [P.text.query_terms(t) if t else [] for t in texts]
+    corpus = orc.OracleCorpus(emb, created, contents)
+    check = {0, 1, 2, 3, 64, 65, 69, 127, 129, 199, 255, 256, 257, 299}
+    for nb in (70, 128, 130, 256, 300):
+        idx.set_profiling(True)
+        idx.reset_search_stats()
+        rows, scores, counts = idx.search(qs[:nb], terms[:nb], NOW, 10, candidate_limit=n)
+        st = idx.kernel_stats()
+        ss = idx.search_stats()
+        idx.set_profiling(False)
+        assert st["screen_i8_fused"]["launches"] >= 1 and "dot_exact" not in st, sorted(st)
+        assert ss["exact_pass_queries"] == 0, ss                          # nothing had to fall back to the exact pass
+        for b in sorted(x for x in check if x < nb):
+            orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+            assert list(rows[b, :counts[b]]) == list(orow), (nb, b)
+            assert np.array_equal(scores[b, :counts[b]], osc), (nb, b)
+    # the same answers with the two-stage pass switched off (exact kernels only)
+    idx.set_option("two_stage", 0)
+    rows0, scores0, counts0 = idx.search(qs[:130], terms[:130], NOW, 10, candidate_limit=n)
+    idx.set_option("two_stage", 1)
+    rows1, scores1, counts1 = idx.search(qs[:130], terms[:130], NOW, 10, candidate_limit=n)
+    assert np.array_equal(counts0, counts1) and np.array_equal(rows0, rows1) and np.array_equal(scores0, scores1)
+    idx.close()

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r2
-bash tools/bench_sweep.sh > gpurun_out/r2/sweep.log 2>&1; tail -22 gpurun_out/r2/sweep.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "four_wave" > gpurun_out/r2/t4w.log 2>&1; tail -15 gpurun_out/r2/t4w.log
