@@ -273,7 +273,7 @@ def run_leg(leg, args, env, idx, front, gen, overlap=False):
         "query_tokenisation_ms_per_step": 1e3 * tok_s / max(1, n_steps_total),
         "query_tokenisation": "host half of KeywordScore (split / lower / distinct / stop words, then packed into the ABI arrays) "
                               "done before the timed region; its cost per step is this field",
-        "roofline": roofline_of(stats, leg.rows_per_gpu, dim, B),
+        "roofline": roofline_of(stats, leg.rows_per_gpu, dim, B, args.steps),
         "search_stats": sstats,
         "kernels": {n: {"launches": v["launches"], "avg_ms": v["total_ms"] / max(1, v["launches"])} for n, v in stats.items()},
         "kernels_source": "the kernel that streams every row: HIP events over the timed steps; the others: HIP events over 5 untimed steps after them",
@@ -300,7 +300,7 @@ def _committed_traffic(kernel, rows, dim, B):
     return None, None
 
 
-def roofline_of(stats, rows, dim, B):
+def roofline_of(stats, rows, dim, B, steps):
     """The dominant kernel of the leg against its roofline.  `achieved` is priced on the bytes / operations the kernel
     really performs (it streams the int8 shadow: N*D bytes); `frac_survey_8d` prices the same launch on SURVEY.md
     §8(d)'s fp32 figure 4*N*D, which this kernel does not read -- a value > 1 there says exactly that."""
@@ -325,19 +325,25 @@ def roofline_of(stats, rows, dim, B):
         if a:
             ms, bytes_per_launch = a
             i8 = name == "screen_i8_fused"
-            ops = 2.0 * B * rows * dim
+            # large shards take the screening GEMM in several row ranges, one launch each (orr_api.hip): everything below is per
+            # LAUNCH, as the contract asks -- rows, operations and the committed PMC traffic of a step divided by its launches
+            per_step = max(1, int(round(stats[name]["launches"] / max(1, steps))))
+            ops = 2.0 * B * rows * dim / per_step
             mfma_peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_BF16_PEAK_TFLOPS
             crossover = I8_CROSSOVER_B if i8 else I8_CROSSOVER_B / 2.0 * (MFMA_BF16_PEAK_TFLOPS / MFMA_I8_PEAK_TOPS) * 2.0
             gbs = bytes_per_launch / (ms * 1e-3) / 1e9
             tops = ops / (ms * 1e-3) / 1e12
             traffic, src = _committed_traffic(name, rows, dim, B)
+            if traffic is not None:
+                traffic /= per_step
             hbm_bound = B < crossover
             r = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
                  "achieved": gbs if hbm_bound else tops, "peak": HBM_PEAK_GBS if hbm_bound else mfma_peak,
                  "unit": "GB/s" if hbm_bound else ("TOP/s" if i8 else "TFLOP/s"),
                  "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tops / mfma_peak),
                  "traffic": traffic, "traffic_source": src, "avg_launch_ms": ms,
-                 "algo_bytes_per_launch": bytes_per_launch, "algo_ops_per_launch": ops,
+                 "algo_bytes_per_launch": bytes_per_launch, "algo_ops_per_launch": ops, "launches_per_step": per_step,
+                 "avg_ms_per_step_in_this_kernel": ms * per_step,
                  "basis": ("rows of the %s shadow streamed once per launch (N*D%s bytes) + the query image; bound chosen from the batch "
                            "against the dtype's crossover (%.0f queries)" % ("int8" if i8 else "bf16", "" if i8 else "*2", crossover)),
                  "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
@@ -346,8 +352,8 @@ def roofline_of(stats, rows, dim, B):
                                   "sustained_peak_source": "tools/mfma_rate.hip on this chip: MFMA-only, one wave per SIMD, all CUs "
                                                            "(profiles/r02_mfma_rate_microbench.txt): 32.3 cycles per MFMA at the 1.61 GHz "
                                                            "the chip holds under that load"} if i8 else {})),
-                 "frac_survey_8d": survey_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "survey_8d_bytes_per_launch": survey_bytes}
+                 "frac_survey_8d": survey_bytes / per_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "survey_8d_bytes_per_launch": survey_bytes / per_step}
             return r
     return None
 

@@ -133,7 +133,7 @@ struct orr_index {
     int64_t row_base = 0;
     hipStream_t stream = nullptr;      // main stream: dots, fused score, selection
     hipStream_t stream_kw = nullptr;   // keyword scan runs beside the HBM-bound dot kernel
-    hipEvent_t ev_inputs = nullptr, ev_kw_done = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_kw_done = nullptr, ev_main_ready = nullptr, ev_range[3] = {nullptr, nullptr, nullptr};
     std::mutex mu;
 
     // corpus, in append order until seal, in candidate order afterwards
@@ -517,6 +517,10 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
         hipStreamCreateWithFlags(&idx->stream_kw, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_inputs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_range[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_range[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_range[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_q, hipEventDisableTiming) != hipSuccess) {
         orr_index_destroy(idx);
         return fail(ORR_EDEVICE, "cannot create streams on device %d", cfg->device);
@@ -537,6 +541,8 @@ void orr_index_destroy(orr_index *idx)
     if (idx->stream_kw) (void)hipStreamSynchronize(idx->stream_kw);
     if (idx->ev_inputs) (void)hipEventDestroy(idx->ev_inputs);
     if (idx->ev_kw_done) (void)hipEventDestroy(idx->ev_kw_done);
+    if (idx->ev_main_ready) (void)hipEventDestroy(idx->ev_main_ready);
+    for (hipEvent_t e : idx->ev_range) if (e) (void)hipEventDestroy(e);
     if (idx->stream_kw) (void)hipStreamDestroy(idx->stream_kw);
     for (auto &pe : idx->pending) { (void)hipEventDestroy(pe.start); (void)hipEventDestroy(pe.stop); }
     for (auto e : idx->event_pool) (void)hipEventDestroy(e);
@@ -1142,6 +1148,10 @@ int orr_index_view(orr_index *parent, orr_index **out)
         hipStreamCreateWithFlags(&v->stream_kw, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_inputs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_range[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_range[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_range[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_q, hipEventDisableTiming) != hipSuccess) {
         orr_index_destroy(v);
         return fail(ORR_EDEVICE, "cannot create streams on device %d", parent->device);
@@ -1750,10 +1760,21 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             orr::FusedEpilogue epi{};
             epi.count_planes = nullptr;
             epi.plane_stride = (n + 63) / 64 * 64;
+            // Large shards go through the int8 screening GEMM in FOUR ROW RANGES: only the first range's count words are formed
+            // in front of the GEMM; those of the later ranges are formed on the keyword stream while the earlier ranges are
+            // multiplied (the GEMM leaves half of the HBM bandwidth unused; in front of it the count words were 0.5 of the
+            // 1.6 ms a 10M-row, 256-query batch spends before its GEMM starts, 2.7 of 6.9 ms at 12.5M rows x 1024 queries).
+            int n_ranges = 1;
+            int64_t range_row[5] = {0, n, n, n, n};
+            const double plane_bytes_per_row = 4.0 * orr::kCountPlanes * (double)((B + 31) / 32);
             if (kw.bitmaps && !ts_gemv) {
-                Timed t(idx, "count_planes", 4.0 * orr::kCountPlanes * (double)((B + 31) / 32) * (double)n);
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
-                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s));
+                if (prefix_i8 && two_stage && n >= (int64_t)2000000) {
+                    n_ranges = 4;
+                    for (int r = 1; r < 4; ++r) range_row[r] = (n * r / 4) / 256 * 256;
+                }
+                Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[1] - range_row[0]));
+                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, 0, range_row[1]));
                 epi.count_planes = idx->ws_fany.as<uint32_t>();
             }
             epi.qf = idx->ws_fqf.as<float4>();
@@ -1841,6 +1862,11 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                            idx->ws_fqf.as<float4>(), s, gemm_i8 ? idx->ws_q8s1.as<float>() : nullptr,
                                                            gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr));
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
+                if (n_ranges > 1 && !gemm_i8) {         // (ranges were planned for the int8 GEMM: the other forms take one launch)
+                    Timed t(idx, "count_planes", plane_bytes_per_row * (double)(n - range_row[1]));
+                    HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, range_row[1], n));
+                    n_ranges = 1;
+                }
                 if (gemm_i8) {
                     if (!prefix_i8) {
                         ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
@@ -1848,9 +1874,27 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     }
                     // algorithmic bytes: the int8 rows once, per row its constants (rowc 16 B, i8_rowf 16 B) and, with query terms,
                     // 16 B of count words per 32 queries; the query image once
-                    Timed t(idx, "screen_i8_fused", (double)n * ((double)idx->dim + 32.0 + (epi.count_planes ? 16.0 * (double)((B + 31) / 32) : 0.0)) +
-                                                    1.0 * (double)B * idx->dim);
-                    HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, n, idx->dim, epi, s));
+                    if (n_ranges > 1) {
+                        // the later ranges' count words: released when the main stream reaches the first range's GEMM
+                        hipStream_t k = idx->stream_kw;
+                        HIP_TRY(hipEventRecord(idx->ev_main_ready, s));
+                        HIP_TRY(hipStreamWaitEvent(k, idx->ev_main_ready, 0));
+                        for (int r = 1; r < n_ranges; ++r) {
+                            {
+                                Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[r + 1] - range_row[r]), k);
+                                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), k, range_row[r],
+                                                                       range_row[r + 1]));
+                            }
+                            HIP_TRY(hipEventRecord(idx->ev_range[r - 1], k));
+                        }
+                    }
+                    for (int r = 0; r < n_ranges; ++r) {
+                        if (r > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_range[r - 1], 0));
+                        const double rows_r = (double)(range_row[r + 1] - range_row[r]);
+                        Timed t(idx, "screen_i8_fused", rows_r * ((double)idx->dim + 32.0 + (epi.count_planes ? 16.0 * (double)((B + 31) / 32) : 0.0)) +
+                                                        1.0 * (double)B * idx->dim);
+                        HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, range_row[r + 1], idx->dim, epi, s, range_row[r]));
+                    }
                 } else if (ts_i8) {
                     Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 28.0 * (double)n + 2.0 * (double)B * idx->dim);   // per row: scale, two relative norms (12 B), normB and created (16 B)
                     HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
 // queries down the lanes and rows along the bits, is transposed across the lanes with five exchange
 // steps, after which lane (r, h) holds the word of row r.  words_per_term % 4 == 0.
 __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride,
-                                                                uint32_t *__restrict__ planes)
+                                                                uint32_t *__restrict__ planes, int64_t oct_first, int64_t oct_end)
 {
     const int g = blockIdx.y;
     const int32_t n_qg = gridDim.y;
@@ -263,9 +263,9 @@ __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int3
     uint32_t t0 = 0, t1 = 0;
     if (b < B) { t0 = kw.q_term_off[b]; t1 = kw.q_term_off[b + 1]; }
     const bool saturate = t1 - t0 > 15u;
-    const int64_t n_quads = kw.words_per_term >> 2, n_oct = (n_quads + 1) >> 1;
+    const int64_t n_quads = kw.words_per_term >> 2;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t pr = wave_id; pr < n_oct; pr += n_waves) {
+    for (int64_t pr = oct_first + wave_id; pr < oct_end; pr += n_waves) {
         const int64_t Q = pr * 2 + h;                                      // this half-wave's group of four words
         uint32_t c[4][kCountPlanes];
 #pragma unroll
@@ -332,15 +332,19 @@ __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int3
     }
 }
 
-hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s)
+hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s,
+                                     int64_t row_first, int64_t row_end)
 {
     if (B <= 0 || !kw.bitmaps || n_rows <= 0) return hipSuccess;
-    if (kw.words_per_term % 4 != 0) return hipErrorInvalidValue;
-    const int64_t n_oct = (kw.words_per_term / 4 + 1) / 2;
-    int64_t bx = (n_oct + 3) / 4;                                          // 4 waves per workgroup
+    if (kw.words_per_term % 4 != 0 || row_first % 256 != 0) return hipErrorInvalidValue;
+    const int64_t n_oct = (kw.words_per_term / 4 + 1) / 2;                 // 256 rows each
+    const int64_t oct_first = row_first / 256;
+    const int64_t oct_end = row_end < 0 ? n_oct : std::min<int64_t>(n_oct, (row_end + 255) / 256);
+    if (oct_end <= oct_first) return hipSuccess;
+    int64_t bx = (oct_end - oct_first + 3) / 4;                            // 4 waves per workgroup
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(query_count_planes_kernel, dim3((unsigned)bx, (unsigned)((B + 31) / 32)), dim3(256), 0, s, kw, B, n_rows,
-                       plane_stride, planes);
+                       plane_stride, planes, oct_first, oct_end);
     return hipGetLastError();
 }
 

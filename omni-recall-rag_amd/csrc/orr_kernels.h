@@ -170,7 +170,9 @@ struct FusedEpilogue {
 hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_split_ws, hipStream_t s);
 hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
                                   float *S, int64_t s_stride, const FusedEpilogue *epi, int32_t products, hipStream_t s);
-hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s);
+// rows [row_first, row_end) only (row_first % 256 == 0; row_end < 0: to the end)
+hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s,
+                                     int64_t row_first = 0, int64_t row_end = -1);
 hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s,
                                      const float *i8_qs1 = nullptr, const double *i8_qerr2 = nullptr);
 // K2c (orr_screen.hip): plain-bf16 screening GEMM (256 x 256 x 64 tiles, LDS-DMA staging) over TILED bf16
@@ -202,8 +204,10 @@ hipError_t launch_screen_gemv_i8(const void *q12, const float *s1, const double 
 // Queries: ONE int8 level (q1 of launch_i8_queries, err2_l1), tiled like the rows; epi must carry i8_rowf / i8_qs1.
 hipError_t launch_i8_rowf(const float *scale, const float *rel_err, const float *rel_hat, int64_t n_rows, float4 *rowf, hipStream_t s);
 hipError_t launch_i8_tile_queries(const void *q1_linear, int32_t B, int32_t D, void *tiled, hipStream_t s);
+// rows [row_first, n_rows) (row_first % 256 == 0): a launch per row range lets the count words of later ranges be formed
+// while earlier ranges are multiplied
 hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D,
-                            const FusedEpilogue &epi, hipStream_t s);
+                            const FusedEpilogue &epi, hipStream_t s, int64_t row_first = 0);
 // The same product over rows [0, n_rows) with the integer dots written out: S[b][r] = (float)I (the sampled prefix).
 hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, float *S,
                                  int64_t s_stride, hipStream_t s);

@@ -9,6 +9,10 @@
 // bound of the query's k-th best score; everything it keeps is re-scored in the reference's own
 // arithmetic (RecallSearchService.cs:77-87) by rescore_buffer_exact (orr_gemm.hip).
 //
+// Two forms of the same 256 x 256 tile live here: the eight-wave one described next (up to 64 queries, the unfused
+// prefix product, the bf16 shadow) and, further down, the four-wave one (screen_tile4_kernel: one wave per SIMD, from 65
+// queries on the int8 shadow, where the matrix cores carry the launch).
+//
 // Structure (gfx950): one 256 (queries) x 256 (rows) tile per workgroup, 8 waves as 2 x 4, each
 // wave 128 x 64 = 4 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator VGPRs).
 // Both operands are bf16 with k contiguous, so both go global -> LDS with
@@ -1079,11 +1083,11 @@ hipError_t launch_i8_tile_queries(const void *q1_linear, int32_t B, int32_t D, v
 
 // The int8 screening GEMM over all rows with the fused epilogue (epi.i8_rowf / epi.i8_qs1 set).
 hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D,
-                            const FusedEpilogue &epi, hipStream_t s)
+                            const FusedEpilogue &epi, hipStream_t s, int64_t row_first)
 {
-    if (B <= 0 || n_rows <= 0) return hipSuccess;
-    if (D <= 0 || D % 128 != 0 || !epi.i8_rowf || !epi.i8_qs1) return hipErrorInvalidValue;
-    const int64_t n_ntiles = (n_rows + kScBN - 1) / kScBN;
+    if (B <= 0 || n_rows <= row_first) return hipSuccess;
+    if (D <= 0 || D % 128 != 0 || !epi.i8_rowf || !epi.i8_qs1 || row_first % kScBN != 0 || row_first < 0) return hipErrorInvalidValue;
+    const int64_t n_ntiles = (n_rows - row_first + kScBN - 1) / kScBN;
     const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
@@ -1104,14 +1108,14 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<true, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
-                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
 #define ORR_LAUNCH_I8W4(L, NT) do { \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_tile4_kernel<true, true, L, NT>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kS4Lds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_tile4_kernel<true, true, L, NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
-                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
     // From 65 queries up (two or more live 32-query tiles per wave... the matrix cores carry the launch) the four-wave form
     // of the tile; below, the eight-wave form (HBM-bound there, and its two waves per SIMD hide the epilogue's latencies).

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r2
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "four_wave" > gpurun_out/r2/t4w.log 2>&1; tail -15 gpurun_out/r2/t4w.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2/t_all.log 2>&1; tail -3 gpurun_out/r2/t_all.log
+bash tools/profile_round.sh > gpurun_out/r2/profile_round.log 2>&1; tail -3 gpurun_out/r2/profile_round.log
