@@ -288,16 +288,17 @@ def _committed_traffic(kernel, rows, dim, B):
     runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), only where the shape matches."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, None, 1
     try:
         with open(path) as f:
             doc = json.load(f)
         for e in doc.get("entries", []):
             if e.get("kernel") == kernel and e.get("rows") == rows and e.get("dim") == dim and e.get("batch") == B:
-                return e.get("hbm_bytes_per_launch_corrected"), "profiles/r02_pmc_hbm_traffic.json (" + e.get("command", "") + ")"
+                return (e.get("hbm_bytes_per_launch_corrected"), "profiles/r02_pmc_hbm_traffic.json (" + e.get("command", "") + ")",
+                        int(e.get("launches_per_step", 1)))
     except Exception:
         pass
-    return None, None
+    return None, None, 1
 
 
 def roofline_of(stats, rows, dim, B, steps):
@@ -313,7 +314,7 @@ def roofline_of(stats, rows, dim, B, steps):
         if a:
             ms, bytes_per_launch = a
             achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-            traffic, src = _committed_traffic(name, rows, dim, B)
+            traffic, src, _ = _committed_traffic(name, rows, dim, B)
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": ms,
                     "algo_bytes_per_launch": bytes_per_launch,
@@ -333,9 +334,9 @@ def roofline_of(stats, rows, dim, B, steps):
             crossover = I8_CROSSOVER_B if i8 else I8_CROSSOVER_B / 2.0 * (MFMA_BF16_PEAK_TFLOPS / MFMA_I8_PEAK_TOPS) * 2.0
             gbs = bytes_per_launch / (ms * 1e-3) / 1e9
             tops = ops / (ms * 1e-3) / 1e12
-            traffic, src = _committed_traffic(name, rows, dim, B)
+            traffic, src, committed_per_step = _committed_traffic(name, rows, dim, B)
             if traffic is not None:
-                traffic /= per_step
+                traffic *= committed_per_step / per_step          # (the committed figure is per launch of ITS run)
             hbm_bound = B < crossover
             r = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
                  "achieved": gbs if hbm_bound else tops, "peak": HBM_PEAK_GBS if hbm_bound else mfma_peak,
