@@ -1322,6 +1322,10 @@ thread_local HostTiming g_ht;          // per searching thread: lanes (views) an
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
 // the query vectors in host memory (valid until the next call).  Caller holds the lock.
+// up to this many queries the tail of the two-stage pass is one launch (finish_survivors: four lanes per survivor; 1M x 3072
+// rows, 128 / 256 queries: 1.016 -> 0.984 / 1.43 -> 1.39 ms per batch; 10M rows x 256: even; beyond, the survivors of a batch
+// are too many for four lanes each)
+constexpr int kFinishFusedMaxB = 256;
 constexpr int kRetryPass = 1;          // run_shard_once: a workspace was too small and has been enlarged; the same pass again
 
 int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
@@ -1914,7 +1918,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 }
                 ORR_TRY(idx->ws_fdot.reserve(sizeof(double) * (size_t)B * kCap));
                 ORR_TRY(idx->pin_cnt.reserve(sizeof(uint32_t) * (size_t)B));
-                if (B <= 64 && idx->dim % 256 == 0) {
+                if (B <= kFinishFusedMaxB && idx->dim % 256 == 0) {
                     // the tail in one launch; small record sets go straight into pinned host memory (they are final when written)
                     if (host_records && !a.out_dev && rec_bytes <= (256u << 10)) {
                         ORR_TRY(idx->pin_cand.reserve(rec_bytes));

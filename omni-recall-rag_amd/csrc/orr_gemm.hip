@@ -608,7 +608,7 @@ __device__ __forceinline__ double quad_step(double acc, const double (&prod)[64]
     return quad_broadcast<S>(acc);
 }
 
-// The whole tail of a two-stage pass in ONE launch (up to 64 queries; each launch boundary on this chain costs a
+// The whole tail of a two-stage pass in ONE launch (up to 256 queries; each launch boundary on this chain costs a
 // one-query search about 10 us of idle GPU): a workgroup of four waves takes 64 survivors of one query,
 //   1. re-scores them as above (16 per wave) and overwrites their keys, dots to buf_dot;
 //   2. sorts its 64 (key, row) pairs into lists[b][y];
@@ -784,7 +784,7 @@ hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q
 {
     if (B <= 0) return hipSuccess;
     if (D % 64 != 0) return hipErrorInvalidValue;
-    // one row per lane (large batches; up to 64 queries go through launch_finish_survivors, four lanes per survivor)
+    // one row per lane (large batches; up to 256 queries go through launch_finish_survivors, four lanes per survivor)
     hipLaunchKernelGGL(rescore_buffer_exact_kernel<false>, dim3((unsigned)B, cap / 64), dim3(64), 0, s, E, D, Q, norm_b, created, kw, qc,
                        now_ticks, cnt, cap, buf, buf_dot);
     return hipGetLastError();

@@ -215,7 +215,7 @@ hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_t
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
                                        const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,
                                        const uint32_t *cnt, uint32_t cap, SelEntry *buf, double *buf_dot, hipStream_t s);
-// Up to 64 queries, D % 256 == 0: re-score + lists + final selection + records with exact dots in one launch (done: [B]
+// Up to 256 queries (the caller's choice), D % 256 == 0: re-score + lists + final selection + records with exact dots in one launch (done: [B]
 // zeroed counters; recs / cnt_host may be pinned host memory).
 hipError_t launch_finish_survivors(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b, const int64_t *created,
                                    const int64_t *row_ids, KwView kw, const QueryConst *qc, int64_t now_ticks, const uint32_t *cnt,

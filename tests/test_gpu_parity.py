@@ -631,13 +631,13 @@ def test_two_stage_pass_at_a_dimension_that_is_a_multiple_of_256():
     texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
     terms = [P.text.query_terms(t) for t in texts]
     corpus = orc.OracleCorpus(emb, created, contents)
-    for b0, nb in ((0, 1), (0, 4), (1, 7), (0, 17), (0, 64), (0, 70)):     # 70: the one-row-per-lane form again
+    for b0, nb in ((0, 1), (0, 4), (1, 7), (0, 17), (0, 64), (0, 70)):
         idx.set_profiling(True)
         rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
         st = idx.kernel_stats()
         idx.set_profiling(False)
-        # up to 64 queries: the one-launch tail (finish_survivors); beyond, the separate kernels
-        assert ("finish_survivors" if nb <= 64 else "rescore_buffer_exact") in st and "dot_exact" not in st, sorted(st)
+        # up to 256 queries: the one-launch tail (finish_survivors); beyond, the separate kernels
+        assert ("finish_survivors" if nb <= 256 else "rescore_buffer_exact") in st and "dot_exact" not in st, sorted(st)
         for b in sorted({0, min(1, nb - 1), nb - 1}):
             orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (b0, nb, b)
