@@ -42,10 +42,10 @@ HBM_PEAK_GBS = 8000.0            # HBM3E spec; 6.29 TB/s is the measured copy ce
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 MFMA_I8_PEAK_TOPS = 5000.0
 # What the matrix cores of a whole MI355X sustain on v_mfma_i32_32x32x32_i8 with NOTHING else going on (tools/mfma_rate.hip, one
-# wave per SIMD on all 256 CUs, profiles/r02_mfma_rate_microbench.txt): 32.3 cycles per MFMA, but the chip holds 1.61 GHz
-# under that load, not 2.4 -- 65536 ops x 1024 SIMDs / (32.3 / 1.61e9 s).  The dense peak above is never reachable for a
+# wave per SIMD on all 256 CUs, profiles/r02_mfma_rate_microbench.txt): 32.1 cycles per MFMA, but the chip holds 1.60 GHz
+# under that load, not 2.4 -- 65536 ops x 1024 SIMDs / (32.1 / 1.60e9 s).  The dense peak above is never reachable for a
 # full-chip launch of a millisecond or more; reported beside it, not instead of it.
-MFMA_I8_SUSTAINED_TOPS = 65536.0 * 1024.0 / (32.3 / 1.61e9) / 1e12       # ~3345
+MFMA_I8_SUSTAINED_TOPS = 65536.0 * 1024.0 / (32.1 / 1.60e9) / 1e12       # ~3345
 I8_CROSSOVER_B = MFMA_I8_PEAK_TOPS * 1e12 / (HBM_PEAK_GBS * 1e9) / 2.0     # queries per int8 row byte: 312.5
 
 
@@ -351,7 +351,7 @@ def roofline_of(stats, rows, dim, B, steps):
                  "mfma": dict({"achieved": tops, "peak": mfma_peak, "unit": "TOP/s" if i8 else "TFLOP/s", "frac": tops / mfma_peak},
                               **({"sustained_peak": MFMA_I8_SUSTAINED_TOPS, "frac_of_sustained": tops / MFMA_I8_SUSTAINED_TOPS,
                                   "sustained_peak_source": "tools/mfma_rate.hip on this chip: MFMA-only, one wave per SIMD, all CUs "
-                                                           "(profiles/r02_mfma_rate_microbench.txt): 32.3 cycles per MFMA at the 1.61 GHz "
+                                                           "(profiles/r02_mfma_rate_microbench.txt): 32.1 cycles per MFMA at the 1.60 GHz "
                                                            "the chip holds under that load"} if i8 else {})),
                  "frac_survey_8d": survey_bytes / per_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "survey_8d_bytes_per_launch": survey_bytes / per_step}
