@@ -224,16 +224,18 @@ int ensure_index(orrh_service *svc)
         if (!stale.empty() && !changed) {
             if (sh.dead.empty()) sh.dead.assign(sh.chunks.size(), 0);
             std::vector<int64_t> ids;
+            std::vector<size_t> marked;
             for (size_t p = 0; p < sh.chunks.size(); ++p)
                 if (!sh.dead[p] && std::binary_search(stale.begin(), stale.end(), sh.chunks[p].document_id)) {
                     ids.push_back(sh.id_base + (int64_t)p);
-                    sh.dead[p] = 1;
+                    marked.push_back(p);
                 }
             int64_t done = 0;
             const int r = orr_index_delete_rows(sh.index, (int64_t)ids.size(), ids.data(), &done);
             if (r == ORR_ESTATE) changed = true;              // too much of the shard is gone: rebuild below
-            else if (r != ORR_OK) return fail(r, orr_last_error());
+            else if (r != ORR_OK) return fail(r, orr_last_error());     // (nothing was marked: the mirror still matches the index)
             else {
+                for (size_t p : marked) sh.dead[p] = 1;       // only once the index has dropped them
                 sh.n_dead += done;
                 svc->tombstoned_rows += done;
                 for (const auto &d : stale) sh.doc_stamps.erase(d);

@@ -476,6 +476,25 @@ constexpr double kCertifyEps = 1e-13;
 
 }  // namespace
 
+namespace {
+
+// Shard file -> device array whose values index something (orr_index_load): every element is checked on its way through the host buffer
+// (a shard file is input: posting rows >= n_rows would make expand_hits write outside the term bitmaps).
+template <typename T, typename CHECK>
+int read_device_array_checked(FILE *f, T *dptr, size_t count, std::vector<uint8_t> &buf, CHECK ok_run, const char *what)
+{
+    const size_t per = buf.size() / sizeof(T);
+    for (size_t off = 0; off < count; off += per) {
+        const size_t m = std::min(per, count - off);
+        if (fread(buf.data(), sizeof(T), m, f) != m) return fail(ORR_EINVAL, "shard file is truncated");
+        if (!ok_run(reinterpret_cast<const T *>(buf.data()), off, m)) return fail(ORR_EINVAL, "shard file: malformed %s", what);
+        HIP_TRY(hipMemcpy(dptr + off, buf.data(), m * sizeof(T), hipMemcpyHostToDevice));
+    }
+    return ORR_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int orr_abi_version(void) { return ORR_ABI_VERSION; }
@@ -875,6 +894,19 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
         fclose(f);
         return fail(ORR_EDIM, "orr_index_load: file dimension %u differs from the requested %d", h.dim, cfg->dim);
     }
+    {   // the header's counts against the size of the file, before anything is allocated from them
+        long at = ftell(f), end = -1;
+        if (at >= 0 && fseek(f, 0, SEEK_END) == 0) end = ftell(f);
+        if (at < 0 || end < 0 || fseek(f, at, SEEK_SET) != 0) { fclose(f); return fail(ORR_EINVAL, "orr_index_load: cannot size %s", path); }
+        const long double nn = (long double)h.n_rows, vv = (long double)h.n_tokens;
+        long double want = (long double)sizeof(h) + nn * (4.0L * h.dim + 8 + 8 + 8 + 4) + (long double)h.n_postings * 4 + (long double)h.reserved[0] * 8;
+        if (h.n_tokens) want += vv * 12 + (long double)h.vpool_bytes;
+        if (h.n_rows) want += (vv + 1) * 8;
+        if (want != (long double)end) {
+            fclose(f);
+            return fail(ORR_EINVAL, "orr_index_load: %s: the header's counts do not add up to the file's size", path);
+        }
+    }
     orr_config c = *cfg;
     c.dim = (int32_t)h.dim;
     c.capacity_rows = h.n_rows;
@@ -903,17 +935,33 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
             ORR_TRY(dev_alloc(&idx->d_vstart, V));
             ORR_TRY(dev_alloc(&idx->d_vlen, V));
             ORR_TRY(dev_alloc(&idx->d_vpool, (size_t)h.vpool_bytes + orr::kScanPoolSlack));
-            ORR_TRY(read_device_array(f, idx->d_vstart, sizeof(uint64_t) * V, buf));
-            ORR_TRY(read_device_array(f, idx->d_vlen, sizeof(uint32_t) * V, buf));
+            std::vector<uint64_t> vstart_h(V);
+            ORR_TRY(read_device_array_checked(f, idx->d_vstart, V, buf, [&](const uint64_t *x, size_t off, size_t m) {
+                for (size_t i = 0; i < m; ++i) { if (x[i] > h.vpool_bytes) return false; vstart_h[off + i] = x[i]; }
+                return true; }, "vocabulary offsets"));
+            ORR_TRY(read_device_array_checked(f, idx->d_vlen, V, buf, [&](const uint32_t *x, size_t off, size_t m) {
+                for (size_t i = 0; i < m; ++i) if (vstart_h[off + i] + orr::padded_row_bytes(x[i]) > h.vpool_bytes) return false;
+                return true; }, "vocabulary lengths"));
             HIP_TRY(hipMemset(idx->d_vpool, 0x20, (size_t)h.vpool_bytes + orr::kScanPoolSlack));
             ORR_TRY(read_device_array(f, idx->d_vpool, (size_t)h.vpool_bytes, buf));
         }
         if (n) {
             ORR_TRY(dev_alloc(&idx->d_post_off, V + 1));
-            ORR_TRY(read_device_array(f, idx->d_post_off, sizeof(uint64_t) * (V + 1), buf));
+            uint64_t prev = 0;
+            ORR_TRY(read_device_array_checked(f, idx->d_post_off, V + 1, buf, [&](const uint64_t *x, size_t off, size_t m) {
+                for (size_t i = 0; i < m; ++i) {
+                    if (x[i] < prev || x[i] > h.n_postings || (off + i == 0 && x[i] != 0) || (off + i == V && x[i] != h.n_postings)) return false;
+                    prev = x[i];
+                }
+                return true; }, "posting offsets"));
+        } else if (h.n_postings) {
+            return fail(ORR_EINVAL, "shard file: postings without rows");
         }
         ORR_TRY(dev_alloc(&idx->d_post_rows, std::max<size_t>((size_t)h.n_postings, 1)));
-        if (h.n_postings) ORR_TRY(read_device_array(f, idx->d_post_rows, sizeof(uint32_t) * (size_t)h.n_postings, buf));
+        if (h.n_postings)
+            ORR_TRY(read_device_array_checked(f, idx->d_post_rows, (size_t)h.n_postings, buf, [&](const uint32_t *x, size_t, size_t m) {
+                for (size_t i = 0; i < m; ++i) if ((uint64_t)x[i] >= (uint64_t)n) return false;
+                return true; }, "posting rows"));
         if (h.reserved[0]) {                          // deleted rows: norms and timestamps in the file are already overwritten
             if (h.reserved[0] > (uint64_t)n) return fail(ORR_EINVAL, "shard file lists more deleted rows than rows");
             idx->dead.resize((size_t)h.reserved[0]);
@@ -1125,10 +1173,10 @@ int orr_index_view(orr_index *parent, orr_index **out)
         ORR_TRY(ensure_i8_shadow(parent));
         if (!parent->i8_ready) ORR_TRY(ensure_shadow(parent));
     }
+    ORR_TRY(ensure_vlong(parent));             // (before the view exists: a failure here must not leak it)
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
-    ORR_TRY(ensure_vlong(parent));
     v->n_vlong = parent->n_vlong;
     v->vlong_start.p = parent->vlong_start.p; v->vlong_len.p = parent->vlong_len.p; v->vlong_id.p = parent->vlong_id.p;   // borrowed
     v->parent = parent; v->dead_before = parent->dead_before;

@@ -349,6 +349,24 @@ def test_shard_file_round_trip(tmp_path):
     trunc.write_bytes(open(path, "rb").read()[:4096])
     with pytest.raises(P.OrrError):
         P.RecallIndex.load(str(trunc))
+    # a file is input: counts that do not add up to its size, and indices that point outside what they index, are refused
+    # (header: magic[8], version u32, dim u32, n_rows i64, n_tokens i64, n_postings u64, vpool_bytes u64, reserved u64[4])
+    good = bytearray(open(path, "rb").read())
+    import struct
+    n_rows_f, n_tokens_f, n_post_f, vpool_f = struct.unpack_from("<qqQQ", good, 16)
+    assert n_rows_f == n and n_post_f > 0 and n_tokens_f > 0
+    inflated = bytearray(good)
+    struct.pack_into("<Q", inflated, 32, n_post_f + (1 << 40))              # a terabyte of postings that the file does not hold
+    (tmp_path / "inflated.orr").write_bytes(bytes(inflated))
+    with pytest.raises(P.OrrError) as ei:
+        P.RecallIndex.load(str(tmp_path / "inflated.orr"))
+    assert ei.value.code == P.native.ORR_EINVAL and "add up" in str(ei.value)
+    wild = bytearray(good)                                                   # the posting rows are the file's last array
+    struct.pack_into("<I", wild, len(wild) - 4, n + 5)                      # (no deleted rows in this shard)
+    (tmp_path / "wild.orr").write_bytes(bytes(wild))
+    with pytest.raises(P.OrrError) as ei:
+        P.RecallIndex.load(str(tmp_path / "wild.orr"))
+    assert ei.value.code == P.native.ORR_EINVAL and "posting rows" in str(ei.value)
     idx.close()
     re.close()
 
