@@ -318,7 +318,7 @@ def roofline_of(stats, rows, dim, B, steps):
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": ms,
                     "algo_bytes_per_launch": bytes_per_launch,
-                    "basis": "bytes this kernel streams per launch (int8 shadow N*D + 12*N row constants + queries; fp32 4*N*D for dot_exact)",
+                    "basis": "bytes this kernel streams per launch (int8 shadow N*D + 28*N of per-row constants + queries; fp32 4*N*D for dot_exact)",
                     "frac_survey_8d": survey_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "survey_8d_bytes_per_launch": survey_bytes}
     for name in ("screen_i8_fused", "screen_bf16_fused"):
