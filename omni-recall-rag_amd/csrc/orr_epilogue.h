@@ -4,12 +4,17 @@
 #include "orr_kernels.h"
 #include "orr_device.h"
 
+#include <type_traits>
+
+#include "orr_screen_tile16_asm.inc"      // ORR_T16_ACC_CLOBBERS
+
 namespace orr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4e __attribute__((ext_vector_type(4)));
 
 // Scoring epilogue shared by the batched kernels.  acc[i][j] are 32 x 32 accumulator tiles of
 // v_mfma_f32_32x32x16_bf16 / v_mfma_i32_32x32x32_i8: element e of lane (fr = lane & 31, fh = lane >> 5) belongs
@@ -155,6 +160,9 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
     }
     if (st) { asm volatile("" :: "v"(cj[0]), "v"(rb[0]), "v"(eb[0])); ORR_EPI_STAMP(4); }
     int parked = 0;
+#ifdef ORR_X_COUNT1B
+    int n_flagged = 0;
+#endif
     // the query constants of (block i, element e) for this lane: {0.7/sqrt(normA) [* s1], floor - margin, 0.2/terms, int8: query part of the bound}
     auto qf_of = [&](int i, int e) -> float4 {
         const int qi = qbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -213,6 +221,9 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
                 if (i == 0) { ORR_EPI_STAMP(5); }
                 continue;
             }
+#ifdef ORR_X_COUNT1B
+            ++n_flagged;
+#endif
         }
         // Pass 1b: the same tests element by element, parking what passes.  With staged inputs it only runs for a block in
         // which 1a found something (about one block in fifteen on the bench corpus).
@@ -254,6 +265,9 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
         if (i == 0) { ORR_EPI_STAMP(5); }
     }
     ORR_EPI_STAMP(6);
+#ifdef ORR_X_COUNT1B
+    if (st && lane == 0) st[7] = (unsigned long long)n_flagged;
+#endif
 #undef ORR_EPI_STAMP
     if (parked > QDEPTH) parked = QDEPTH;
     for (int s = 0; s < parked; ++s) {
@@ -273,6 +287,251 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
         }
         unsigned long long key = score_key(fused_score_fast(dot, rc.x, rc.y, mm, qc) + bound);
         if (!(__builtin_fabsf(pk.a) <= 3.4028234663852886e38f) || !(bound <= 1.7976931348623157e308)) key = ~0ull;   // kept whatever the floor: re-scored exactly later
+        if (key > epi.tau[qi]) {
+            const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
+            if (slot < epi.cap) {
+                SelEntry en;
+                en.key = key; en.pos = (uint32_t)col; en.pad = 0;
+                epi.buf[(int64_t)qi * epi.cap + slot] = en;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same epilogue for 16 x 16 accumulator tiles (v_mfma_i32_16x16x64_i8; the int8 screening GEMM's 128 x 128 wave tile as
+// 8 x 8 tiles of four registers).  Element e of lane (c = lane & 15, g = lane >> 4) of tile (i, j) belongs to query
+// qbase + 16 i + 4 g + e and to row colbase + 16 j + c: a lane holds 8 rows x 32 queries (the 32 x 32 form: 4 x 64).
+// A block of 32 queries is the tile pair (2 b, 2 b + 1); within it the lane's queries are 16 t + 4 g + e (t = 0, 1), whose
+// counts sit in count word 2 t + (g >> 1) at nibble 4 (g & 1) + e -- so a lane needs two of a row's four words per block,
+// shifted by 16 (g & 1) once, and the nibble index is the compile-time e.  Everything else is fused_epilogue's.
+// ---------------------------------------------------------------------------
+struct EpiTileLoads16 {
+    double2 rc[8];
+    float4 rf[8];
+    uint32_t w[4][8][2];           // this lane's count words: [block of 32 queries][row tile][t]
+};
+
+// Word offsets of this lane's count words inside a plane pair: its row (clamped) plus, where g >> 1 is set, the distance to the
+// next plane (word 2 t + 1 instead of 2 t).  32 bits: the launcher sends shards whose planes exceed 2^30 words elsewhere.
+__device__ __forceinline__ void epilogue_word_offsets16(uint32_t (&at)[8], int64_t colbase, int32_t B, int64_t n_rows, const FusedEpilogue &epi,
+                                                        int lane)
+{
+    const int c = lane & 15, g = lane >> 4;
+    const int32_t n_qg = (B + 31) >> 5;
+    const uint32_t plane_dist = epi.count_planes ? (uint32_t)((int64_t)n_qg * epi.plane_stride) : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t col = colbase + j * 16 + c;
+        at[j] = (uint32_t)(col < n_rows ? col : n_rows - 1) + (uint32_t)(g >> 1) * plane_dist;      // clamped, never branched around
+    }
+}
+
+// this lane's two count words per row tile for block b of 32 queries, already shifted to its half (nibble e = query 4 g + e)
+__device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const uint32_t (&at)[8], int b, int qbase, int32_t B,
+                                                      const FusedEpilogue &epi)
+{
+    const int32_t n_qg = (B + 31) >> 5;
+    const bool has_cp = epi.count_planes != nullptr;
+    const int qg = (qbase >> 5) + b;
+    const int qgc = qg < n_qg ? qg : n_qg - 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        // the plane of word 2 t of (query group): a wave-uniform base; the lane's offset picks word 2 t or 2 t + 1
+        const gptr<uint32_t> plane = as_global(has_cp ? epi.count_planes + ((int64_t)(2 * t) * n_qg + qgc) * epi.plane_stride
+                                                      : reinterpret_cast<const uint32_t *>(epi.rowc));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t wv = plane[at[j]];
+            w[j][t] = has_cp ? wv : 0u;
+        }
+    }
+}
+
+__device__ __forceinline__ void epilogue_issue_loads16(EpiTileLoads16 &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
+                                                       const FusedEpilogue &epi, int lane)
+{
+    const int c = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t col = colbase + j * 16 + c;
+        const uint32_t colc = (uint32_t)(col < n_rows ? col : n_rows - 1);     // clamped, never branched around
+        L.rc[j] = load_global(epi.rowc, colc);
+        L.rf[j] = load_global(epi.i8_rowf, colc);
+    }
+    uint32_t at[8];
+    epilogue_word_offsets16(at, colbase, B, n_rows, epi, lane);
+    epilogue_load_words16(L.w[0], at, 0, qbase, B, epi);
+}
+
+// the count words of the blocks 1..3 (behind the K loop: beside the fragments their 48 landing registers did not fit)
+__device__ __forceinline__ void epilogue_issue_later_words16(EpiTileLoads16 &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
+                                                             const FusedEpilogue &epi, int lane)
+{
+    uint32_t at[8];
+    epilogue_word_offsets16(at, colbase, B, n_rows, epi, lane);
+#pragma unroll
+    for (int b = 1; b < 4; ++b) epilogue_load_words16(L.w[b], at, b, qbase, B, epi);
+}
+
+// Registers: the 256 accumulators fill the accumulation file, so everything here has to fit the 256 vector registers with
+// room to spare -- a spilled value comes back through scratch memory behind an s_waitcnt vmcnt(0), which in this kernel also
+// waits for the ring refill in flight.  Hence: three floats per row, one block's count words plus the next block's in
+// flight, the query constants read from LDS one query ahead, 32-bit offsets.
+//
+// The accumulators are not C++ objects here: the K loop is assembler text on fixed registers (tile (i, j), element e =
+// a[4 (8 i + j) + e], orr_screen_tile16_asm.inc), and this epilogue reads them by NUMBER (v_accvgpr_read_b32 vN, aM with M a
+// template constant) -- so every loop over tiles and elements is a compile-time loop.
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// (Not volatile -- the compiler may pair and schedule these freely -- but each takes `token`, a value the K loop's last
+// statement produces: that is the only ordering they need.  a[N]: the immediate prints in hex from 64 up, which the
+// bracket form takes.)
+template <int IDX>
+__device__ __forceinline__ float acc16_as_float(int token)
+{
+    int r;
+    // (the clobber list: on gfx950 the allocator treats accumulation registers as ordinary ones and, under pressure, parks
+    // vector registers there -- over the accumulators it does not know about.  Declaring every read a clobber of all of
+    // them leaves it nothing to keep there across the epilogue.)
+    asm("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(IDX), "v"(token) : ORR_T16_ACC_CLOBBERS);
+    return (float)r;
+}
+
+// the same, volatile: for the rare pass 1b -- a non-volatile asm has no side effects the compiler knows of, so it hoisted all
+// 256 reads of pass 1b (and what hangs on them) out of the `if (block flagged)` around them: 7,000 cycles per tile, always
+template <int IDX>
+__device__ __forceinline__ float acc16_as_float_here(int token)
+{
+    int r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(IDX), "v"(token) : ORR_T16_ACC_CLOBBERS);
+    return (float)r;
+}
+
+template <int QDEPTH, typename HOOK = EpiNoHook>
+__device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
+                                                 const FusedEpilogue &epi, int lane, EpiParked *queue, int queue_stride, uint32_t idx_salt,
+                                                 unsigned long long *st, const EpiTileLoads16 &L, const float4 *qf_lds,
+                                                 HOOK between_blocks = HOOK())
+{
+#define ORR_EPI_STAMP(k) if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime()
+    const int c = lane & 15, g = lane >> 4;
+    const int sh = 16 * (g & 1);
+    float rb[8], cj[8], eb[8];
+    const int64_t col0 = colbase + c;                                      // this lane's row of row tile 0 (tile j: + 16 j)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        rb[j] = (float)L.rc[j].x * L.rf[j].x;                              // the accumulator is the integer dot
+        const float rr = col0 + j * 16 < n_rows ? (float)L.rc[j].y : -__builtin_huge_valf();   // rows past the end never pass
+        cj[j] = rr + L.rf[j].y;
+        eb[j] = L.rf[j].z;
+    }
+    if (st) { asm volatile("" :: "v"(cj[0]), "v"(rb[0]), "v"(eb[0])); ORR_EPI_STAMP(4); }
+    int parked = 0;
+    const float4 *qf_lane = qf_lds + 4 * g;                                // query 16 t + 4 g + e of block b: qf_lane[32 b + 16 t + e]
+    // Pass 1a for all four blocks first, pass 1b (rare, and twenty times the code) for the flagged blocks behind them: with
+    // 1b's code between the blocks' 1a, every block began with a jump over 21 KiB and a cold instruction cache (6,500 cycles
+    // per output tile by the stamps; the accumulators stay where they are, so 1b can read them again later).
+    unsigned long long any_of[4];
+    static_for<4>([&](auto b_c) {
+        constexpr int b = decltype(b_c)::value;
+        between_blocks(b);
+        uint32_t w[8][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[j][0] = L.w[b][j][0] >> sh; w[j][1] = L.w[b][j][1] >> sh; }
+        // Pass 1a, branch-free (see fused_epilogue): could any of the block's 8 x 8 elements of any lane reach its query's floor?
+        unsigned long long wave_any = 0ull;
+        float4 qf = qf_lane[32 * b];
+        static_for<8>([&](auto te_c) {
+            constexpr int te = decltype(te_c)::value, t = te >> 2, e = te & 3;
+            constexpr int nxt = te + 1 < 8 ? 16 * ((te + 1) >> 2) + ((te + 1) & 3) : 0;
+            const float4 qf_next = qf_lane[32 * b + nxt];
+            unsigned long long hit[8];                                      // (OR-ed after the group: see fused_epilogue)
+            static_for<8>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                const uint32_t m = (w[j][t] >> (4 * e)) & 15u;
+                const float a = acc16_as_float<4 * (8 * (2 * b + t) + j) + e>(acc_token);
+                const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
+                hit[j] = __builtin_amdgcn_ballot_w64(!(upper < qf.y));
+            });
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wave_any |= hit[j];
+            // (pinned: the flags are only looked at behind all four blocks, and left alone the compiler postpones the ORs to
+            // there -- parking all 256 masks in vector-register lanes meanwhile and fetching them back one v_readlane at a
+            // time, 7,000 cycles per tile)
+            asm volatile("" : "+s"(wave_any));
+            qf = qf_next;
+        });
+        any_of[b] = wave_any;
+        if constexpr (b == 0) { ORR_EPI_STAMP(5); }
+    });
+#ifdef ORR_X_COUNT1B
+    if (st && lane == 0) st[7] = __builtin_amdgcn_s_memtime();
+#endif
+    int token_1b = acc_token;
+    asm volatile("" : "+v"(token_1b));            // (its own token: pass 1b reads the accumulators again instead of keeping 1a's 256 values)
+    static_for<4>([&](auto b_c) {
+        constexpr int b = decltype(b_c)::value;
+        if (any_of[b] != 0ull) {
+            // Pass 1b: the same tests element by element, parking what passes (about one block in fifteen).  Its count words
+            // come from memory again: kept in registers since pass 1a they were 64 more live values for a rare path.
+            uint32_t at1[8], w1[8][2];
+            epilogue_word_offsets16(at1, colbase, B, n_rows, epi, lane);
+            epilogue_load_words16(w1, at1, b, qbase, B, epi);
+            static_for<8>([&](auto te_c) {
+                constexpr int te = decltype(te_c)::value, t = te >> 2, e = te & 3, i = 2 * b + t;
+                const int qi = qbase + 16 * i + 4 * g + e;
+                const float4 q1 = qf_lane[32 * b + 16 * t + e];
+                const bool has_query = qi < B;
+                static_for<8>([&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    const uint32_t m = ((w1[j][t] >> sh) >> (4 * e)) & 15u;
+                    const float a = acc16_as_float_here<4 * (8 * i + j) + e>(token_1b);
+                    const float upper = __builtin_fmaf((float)m, q1.z, __builtin_fmaf(a, q1.x * rb[j], __builtin_fmaf(q1.w, eb[j], cj[j])));
+                    const bool drop = upper < q1.y || !has_query || !(col0 + j * 16 < n_rows);
+                    if (!drop) {
+                        if (parked < QDEPTH) {
+                            EpiParked pk;
+                            pk.a = a; pk.idx = (uint32_t)((i * 4 + e) * 8 + j) + idx_salt;
+                            queue[parked * queue_stride] = pk;
+                        } else {                                            // every buffer entry gets its exact key afterwards anyway
+                            const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
+                            if (slot < epi.cap) {
+                                SelEntry en;
+                                en.key = ~0ull; en.pos = (uint32_t)(col0 + j * 16); en.pad = 0;
+                                epi.buf[(int64_t)qi * epi.cap + slot] = en;
+                            }
+                        }
+                        ++parked;
+                    }
+                });
+            });
+        }
+    });
+    ORR_EPI_STAMP(6);
+#undef ORR_EPI_STAMP
+    if (parked > QDEPTH) parked = QDEPTH;
+    for (int s = 0; s < parked; ++s) {
+        EpiParked pk = queue[s * queue_stride];
+        pk.idx -= idx_salt;
+        const int j = (int)(pk.idx & 7u), ie = (int)(pk.idx >> 3), e = ie & 3, i = ie >> 2;
+        const int qi = qbase + 16 * i + 4 * g + e;
+        const int64_t col = colbase + j * 16 + c;
+        const QueryConst qc = epi.qc[qi];
+        const double2 rc = epi.rowc[col];
+        const uint32_t mm = qc.n_terms > 0 ? kw_matches(epi.kw, qi, (uint32_t)col) : 0u;
+        const float4 rf = epi.i8_rowf[col];
+        const double dot = (double)pk.a * ((double)rf.x * (double)epi.i8_qs1[qi]);
+        const double bound = (double)rf.y + (double)epi.qf[qi].w * (double)rf.z;
+        unsigned long long key = score_key(fused_score_fast(dot, rc.x, rc.y, mm, qc) + bound);
+        if (!(bound <= 1.7976931348623157e308)) key = ~0ull;               // kept whatever the floor: re-scored exactly later
         if (key > epi.tau[qi]) {
             const uint32_t slot = atomicAdd(&epi.cnt[qi], 1u);
             if (slot < epi.cap) {

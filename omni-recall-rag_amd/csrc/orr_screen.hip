@@ -617,6 +617,248 @@ __global__ __launch_bounds__(256, 1) void screen_tile4_kernel(const __bf16 *__re
 #undef ORR_STAMP
 }
 
+// ---------------------------------------------------------------------------
+// The four-wave tile on v_mfma_i32_16x16x64_i8 (screen_tile16_kernel; 129+ queries on the int8 shadow).  Same rings,
+// requests, barrier protocol, tail, refill and epilogue inputs as screen_tile4_kernel; the 128 x 128 wave tile is 8 x 8
+// accumulator tiles of four registers.  Why: tools/mfma_rate.hip -- with every matrix core busy the chip holds 1.88 GHz on
+// this shape against 1.60 GHz on 32 x 32 x 32 at the same operations per cycle (profiles/r02_mfma_rate_microbench.txt).
+// The stored swizzle was made for 32-row fragments: a 16-row x 4-chunk fragment read is a 2-way bank conflict (LDS
+// cycles, which this kernel has to spare).  The epilogue for this accumulator layout: fused_epilogue16 (orr_epilogue.h).
+// ---------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
+                                                              const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
+                                                              int32_t D, float *__restrict__ S, int64_t s_stride,
+                                                              int32_t n_ntiles, int32_t n_mtiles, int32_t flags, FusedEpilogue epi)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const lds_a = lds, *const lds_b = lds + kS4NA * kScImage, *const lds_epi = lds + (kS4NA + kS4NB) * kScImage;
+    constexpr bool FUSED = true, I8 = true;
+    constexpr int LIVE = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = LIVE == 8 ? wave >> 1 : 0, wc = LIVE == 8 ? wave & 1 : wave;
+    const bool row_loader = wave >= 2;                                      // waves 2, 3 request rows, waves 0, 1 queries
+    constexpr int kPA = LIVE == 8 ? 8 : LIVE == 4 ? 4 : 2;                  // query pieces per K-tile and requesting wave
+    constexpr int kPB = 8;                                                  // row pieces per K-tile and requesting wave
+    const int total_ids = ((n_ntiles + 7) / 8) * 8 * n_mtiles;              // (walk of the output tiles: as in screen_bf16_kernel)
+    auto valid_from = [&](int id) {
+        while (id < total_ids && ((id >> 3) / n_mtiles) * 8 + (id & 7) >= n_ntiles) id += gridDim.x;
+        return id;
+    };
+    const int T = I8 ? D / 64 : D / kScBK;
+    const uint32_t lane_off = (uint32_t)(lane * 16);
+    const uint32_t part_off = row_loader ? (uint32_t)((wave & 1) * kPB * 1024) : (uint32_t)(wave * kPA * 1024);
+    auto stream_src = [&](int sid) -> const unsigned char * {
+        const int smt = (sid >> 3) % n_mtiles, snt = ((sid >> 3) / n_mtiles) * 8 + (sid & 7);
+        return row_loader ? reinterpret_cast<const unsigned char *>(Eh) + ((int64_t)(row_first / kScBN + snt) * T) * kScImage + part_off
+                          : reinterpret_cast<const unsigned char *>(Qh) + ((int64_t)smt * T) * kScImage + part_off;
+    };
+    int s_id = valid_from(blockIdx.x), s_k = 0, s_stage = 0;
+    const unsigned char *s_src = s_id < total_ids ? stream_src(s_id) : nullptr;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(row_loader ? lds_b : lds_a) + part_off;
+    const int ring_n = row_loader ? kS4NB : kS4NA;
+    // NT: the rows are streamed once (the whole batch fits one query tile): requested non-temporal, so they do not push the
+    // query images (re-read by every workgroup) out of L2.  (A template parameter, and the piece index a constant at every
+    // call, and the K loop below exists once per role: a request is M0, a wait state and the load, no branch.)
+    auto issue_piece = [&](auto role, int slot) __attribute__((always_inline)) {
+        constexpr bool ROWS = decltype(role)::value;
+        if constexpr (!ROWS && kPA < kPB) { if (slot >= kPA) return; }
+        // (the immediate offset, applied to both addresses, has 12 bits: pieces 4..7 go through bases 4 KiB further on)
+        const uint32_t m0v = ring_lds + (uint32_t)s_stage * kScImage + (uint32_t)(slot >> 2) * 4096u;
+        const uint64_t src = (uint64_t)(uintptr_t)s_src + (uint64_t)(slot >> 2) * 4096u;
+#define ORR_GLDS(OFF, POLICY) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #OFF POLICY \
+                                           :: "v"(lane_off), "s"(src), "s"(m0v) : "memory")
+        if constexpr (NT && ROWS) {
+            switch (slot & 3) { case 0: ORR_GLDS(0, " nt"); break; case 1: ORR_GLDS(1024, " nt"); break; case 2: ORR_GLDS(2048, " nt"); break; default: ORR_GLDS(3072, " nt"); }
+        } else {
+            switch (slot & 3) { case 0: ORR_GLDS(0, ""); break; case 1: ORR_GLDS(1024, ""); break; case 2: ORR_GLDS(2048, ""); break; default: ORR_GLDS(3072, ""); }
+        }
+#undef ORR_GLDS
+    };
+    auto advance_stream = [&]() {
+        s_stage = s_stage + 1 == ring_n ? 0 : s_stage + 1;
+        if (s_k + 1 < T) { ++s_k; s_src += kScImage; return; }
+        const int nid = valid_from(s_id + gridDim.x);
+        if (nid < total_ids) { s_id = nid; s_k = 0; s_src = stream_src(nid); }
+    };
+    int ring_a = 0, ring_b = 0;
+    bool first = true;
+    int tile_seq = 0;
+#define ORR_STAMP(k) if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + (k)] = __builtin_amdgcn_s_memtime()
+    for (int id = valid_from(blockIdx.x); id < total_ids;) {
+    ORR_STAMP(0);
+    const int next_id = valid_from(id + gridDim.x);
+    const bool has_next = next_id < total_ids;
+    const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
+    const int64_t n0 = row_first + (int64_t)nt * kScBN;
+    const int b0 = mt * kScBM;
+
+    // the accumulators: a[0:255], tile (query tile i, row tile j) = a[4 (8 i + j) .. + 3] -- no C++ object, see the K loop
+    // (zeroed right in front of the first K-tile, so that no compiler-made code runs between the two)
+    int acc_token = 0;
+    int c_a = ring_a, c_b = ring_b;                                         // ring stages of the K-tile whose fragments are read next
+    // 16 x 16 x 64 fragments: lane = (row l & 15, 16-byte chunk l >> 4 of the row's 64 bytes = the whole K-tile); the stored
+    // slot of chunk c in row r is c ^ ((r >> 2) & 3), and (r >> 2) & 3 = (l >> 2) & 3 for every tile of 16 rows
+    const int fo = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4);
+    auto a_at = [&]() { return lds_a + c_a * kScImage + wr * 128 * 64 + fo; };
+    auto b_at = [&]() { return lds_b + c_b * kScImage + wc * 128 * 64 + fo; };
+    auto next_stage = [&]() { c_a = c_a + 1 == kS4NA ? 0 : c_a + 1; c_b = c_b + 1 == kS4NB ? 0 : c_b + 1; };
+    // 64 MFMAs per K-tile (16.3 cycles each), 16 fragment reads, 8 requests.  First half: query tiles 0..3 against all
+    // eight row tiles (row tile varies fastest), the fragments of query tiles 4..7 arriving meanwhile; the barrier; second
+    // half column by column (row tile j against query tiles 4..7), so that row fragment j is free after its column and is
+    // re-read for the NEXT K-tile two columns later -- one register set for the row fragments -- and the next K-tile's query
+    // fragments 0..3 take the registers the first half no longer needs.
+    // The whole K-tile is ONE piece of assembler text (orr_screen_tile16_asm.inc, generated by tools/gen_tile16_asm.py) on
+    // fixed registers -- accumulators a[0:255], fragments v[192:255] (pinned operands of the statement).  With the compiler's
+    // MFMA builtin and all 256 accumulation registers taken, most MFMAs got a copy of their tile in front (100 v_accvgpr_mov
+    // and 61 s_nop per K-tile); with one asm statement per MFMA the allocator moved tiles between code regions right behind
+    // MFMAs whose latency it cannot see (wrong results) or kept copies in vector registers (1,062 spills).  Hazards the text
+    // has to respect itself: a fragment register is overwritten at the earliest 4 MFMAs after its last use (plus the LDS
+    // latency), every fragment read is waited for (lgkmcnt(0) in the middle and at the end) before the half that uses it, and
+    // the accumulators are not read before the s_nops behind the K loop.
+#define ORR_SB __builtin_amdgcn_sched_barrier(0)
+#define ORR_RD(dst, p, i) dst = *reinterpret_cast<const i32x4v *>((p) + (i) * 1024); ORR_SB
+    // The epilogue's one trip to global memory (this thread's query constants for the LDS copy, its rows' constants and
+    // count words, orr_epilogue.h) is requested from INSIDE the K loop, behind the barrier of the last K-tile but one:
+    // a wave's loads return in order, so behind the requests of the next output tile's first K-tiles they would arrive
+    // when that whole ring has (10,000 cycles per tile by the stamps).  Hence also: the last kS4NA / kS4NB iterations
+    // request nothing (their counted waits shrink with what is left in flight), and the ring is refilled for the next
+    // output tile only when the epilogue's inputs are in registers -- it fills while the epilogue computes.
+    FusedEpilogue ep = epi;
+    EpiTileLoads16 pre;
+    float4 qf_mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto epilogue_requests = [&]() __attribute__((always_inline)) {
+        if constexpr (FUSED) {
+            // laundered once per output tile: otherwise everything derived from these is hoisted out of the persistent loop
+            asm volatile("" : "+s"(ep.rowc), "+s"(ep.qc), "+s"(ep.tau), "+s"(ep.qf), "+s"(ep.count_planes), "+s"(ep.plane_stride),
+                              "+s"(ep.i8_rowf), "+s"(ep.i8_qs1), "+s"(ep.cnt), "+s"(ep.buf));
+            asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
+            const int q = b0 + tid;
+            qf_mine = load_global(ep.qf, (uint32_t)(q < B ? q : B - 1));
+            epilogue_issue_loads16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane);
+        }
+    };
+    auto refill = [&](auto role) __attribute__((always_inline)) {          // every stage of this wave's ring requested
+        for (int t = 0; t < ring_n; ++t) {
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) issue_piece(role, sl);
+            advance_stream();
+        }
+    };
+    // (one copy of the loop per requesting role: the counted waits and the request policy are then immediates)
+    auto k_loop = [&](auto role) __attribute__((always_inline)) {
+    constexpr bool ROWS = decltype(role)::value;
+    constexpr int RING = ROWS ? kS4NB : kS4NA, KP = ROWS ? kPB : kPA;
+    if (first) refill(role);
+    first = false;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(KP * (RING - 1)) : "memory");     // tile 0 awaited by its requesters, then visible to everybody
+    i32x4v fa0, fa1, fa2, fa3, fa4, fa5, fa6, fa7, fb0, fb1, fb2, fb3, fb4, fb5, fb6, fb7;     // query fragments 0..7, row fragments 0..7
+    {
+        const unsigned char *pa = a_at(), *pb = b_at();
+        ORR_RD(fa0, pa, 0); ORR_RD(fa1, pa, 1); ORR_RD(fa2, pa, 2); ORR_RD(fa3, pa, 3);
+        ORR_RD(fb0, pb, 0); ORR_RD(fb1, pb, 1); ORR_RD(fb2, pb, 2); ORR_RD(fb3, pb, 3);
+        ORR_RD(fb4, pb, 4); ORR_RD(fb5, pb, 5); ORR_RD(fb6, pb, 6); ORR_RD(fb7, pb, 7);
+        fa4 = fa5 = fa6 = fa7 = fa0;                                           // (defined; read in the first K-tile's first half)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile(ORR_T16_ZERO ::: ORR_T16_ACC_CLOBBERS);
+    // one K-tile.  REQ: its stages are re-requested (K-tile t + RING of this output tile); WAITN: what may stay in flight
+    // when this wave's pieces of K-tile t + 1 have landed; HOOK: the epilogue's requests go out in front of it
+    auto tile_iter = [&](auto req_c, auto waitn_c, auto hook_c) __attribute__((always_inline)) {
+        constexpr bool REQ = decltype(req_c)::value, HOOK = decltype(hook_c)::value;
+        constexpr int WAITN = decltype(waitn_c)::value;
+        if constexpr (HOOK) epilogue_requests();
+        const uint32_t pa = (uint32_t)(uintptr_t)a_at();                     // query fragments 4..7 of this K-tile
+        next_stage();
+        const uint32_t pan = (uint32_t)(uintptr_t)a_at(), pbn = (uint32_t)(uintptr_t)b_at();   // the next K-tile's fragments (read behind the barrier)
+        const uint32_t m0a = ring_lds + (uint32_t)s_stage * kScImage, m0b = m0a + 4096u;
+        const uint64_t srca = (uint64_t)(uintptr_t)s_src, srcb = srca + 4096u;
+#define ORR_T16_OPERANDS \
+            : "+{v[192:195]}"(fa0), "+{v[196:199]}"(fa1), "+{v[200:203]}"(fa2), "+{v[204:207]}"(fa3), \
+              "+{v[208:211]}"(fa4), "+{v[212:215]}"(fa5), "+{v[216:219]}"(fa6), "+{v[220:223]}"(fa7), \
+              "+{v[224:227]}"(fb0), "+{v[228:231]}"(fb1), "+{v[232:235]}"(fb2), "+{v[236:239]}"(fb3), \
+              "+{v[240:243]}"(fb4), "+{v[244:247]}"(fb5), "+{v[248:251]}"(fb6), "+{v[252:255]}"(fb7) \
+            : [pa] "v"(pa), [pan] "v"(pan), [pbn] "v"(pbn), [lo] "v"(lane_off), [m0a] "s"(m0a), [m0b] "s"(m0b), [srca] "s"(srca), \
+              [srcb] "s"(srcb), [wn] "n"(WAITN) \
+            : ORR_T16_ACC_CLOBBERS, "memory"
+        if constexpr (!REQ) asm volatile(ORR_T16_KTILE_NOREQ ORR_T16_OPERANDS);
+        else if constexpr (NT && ROWS) asm volatile(ORR_T16_KTILE_REQ_NT ORR_T16_OPERANDS);
+        else asm volatile(ORR_T16_KTILE_REQ ORR_T16_OPERANDS);
+#undef ORR_T16_OPERANDS
+        if constexpr (REQ) {                                                 // (inside an output tile: no crossing to look for)
+            s_stage = s_stage + 1 == RING ? 0 : s_stage + 1;
+            ++s_k;
+            s_src += kScImage;
+        }
+    };
+    for (int t = 0; t < T - RING; ++t)
+        tile_iter(std::true_type{}, std::integral_constant<int, KP * (RING - 2)>{}, std::false_type{});
+    ORR_STAMP(7);
+    // the last RING K-tiles: r-th of them leaves RING - 2 - r tiles in flight (the last one waits for nothing: 63)
+    auto tail = [&](auto self, auto r_c) __attribute__((always_inline)) {
+        constexpr int r = decltype(r_c)::value;
+        if constexpr (r < RING) {
+            tile_iter(std::false_type{}, std::integral_constant<int, (r <= RING - 2 ? KP * (RING - 2 - r) : 63)>{},
+                      std::integral_constant<bool, r == RING - 2>{});
+            self(self, std::integral_constant<int, r + 1>{});
+        }
+    };
+    tail(tail, std::integral_constant<int, 0>{});
+    int tok_;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\tv_mov_b32 %0, 0" : "=v"(tok_) :: "memory");
+    acc_token = tok_;     // the last fragment reads (into registers about to be reused), the last MFMAs' results; the token orders the epilogue's reads behind this
+    };
+    if (row_loader) k_loop(std::true_type{}); else k_loop(std::false_type{});
+    ORR_STAMP(1);
+
+    {
+        uint32_t salt = 0;
+        asm volatile("" : "+s"(salt));
+        if (b0 + tid >= B) qf_mine = make_float4(0.f, __builtin_huge_valf(), 0.f, 0.f);    // no query: floor +inf
+        EpiParked *queue = reinterpret_cast<EpiParked *>(lds_epi) + tid;
+        float4 *qf_lds = reinterpret_cast<float4 *>(lds_epi + kS4Queue * 8 * 256);
+        qf_lds[tid] = qf_mine;
+        // every loaded register is touched here: the compiler's wait for the loads lands HERE, in front of the refill (further
+        // down it would wait for the refill's requests as well, which are younger)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("" : "+v"(pre.rc[j].x), "+v"(pre.rc[j].y));
+            asm volatile("" : "+v"(pre.rf[j].x), "+v"(pre.rf[j].y), "+v"(pre.rf[j].z), "+v"(pre.rf[j].w));
+            asm volatile("" : "+v"(pre.w[0][j][0]), "+v"(pre.w[0][j][1]));
+        }
+        epilogue_issue_later_words16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane);    // (they land under the first block's tests)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (bare: __syncthreads() would also wait for outstanding requests)
+        unsigned long long *st = (epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
+        // the ring refill for the next output tile rides on the epilogue: a quarter of this wave's requests in front of each
+        // block of 32 queries (the last one takes what is left)
+        auto refill_part = [&](int blk) __attribute__((always_inline)) {
+            if (!has_next) return;
+            auto part = [&](auto role) __attribute__((always_inline)) {
+                constexpr int RING = decltype(role)::value ? kS4NB : kS4NA;
+                const int t0 = blk * RING / 4, t1 = blk + 1 == 4 ? RING : (blk + 1) * RING / 4;
+                for (int t = t0; t < t1; ++t) {
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) issue_piece(role, sl);
+                    advance_stream();
+                }
+            };
+            if (row_loader) part(std::true_type{}); else part(std::false_type{});
+        };
+        fused_epilogue16<kS4Queue>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
+    }
+#undef ORR_RD
+#undef ORR_SB
+    ORR_STAMP(2);
+    if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    ++tile_seq;
+    ring_a = (ring_a + T) % kS4NA;
+    ring_b = (ring_b + T) % kS4NB;
+    id = next_id;
+    }
+#undef ORR_STAMP
+}
+
 // K2g: the same screening pass for 1..8 queries -- no matrix core, a pure stream over the tiled shadow.
 // Work unit = half a row tile (128 rows x D): per K-tile its 8 KiB are eight 1 KiB wave loads, lane l
 // always holding chunk c = (l & 3) ^ ((l >> 4) & 3) of rows 16 j + (l >> 2), j = 0..7 (the swizzle of the
@@ -1121,9 +1363,23 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     // of the tile; below, the eight-wave form (HBM-bound there, and its two waves per SIMD hide the epilogue's latencies).
     // Measured, 1M x 3072 rows: 128 queries 0.756 -> 0.619 ms, 256: 0.862 -> 0.842, 1024: 3.42 -> 3.30; 64: 0.485 vs 0.506.
     if (B > 64 && D / 64 >= kS4NB) {
-        if (B > 256) ORR_LAUNCH_I8W4(8, false);
+#define ORR_LAUNCH_I8W16(NT) do { \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_tile16_kernel<NT>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kS4Lds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_tile16_kernel<NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
+                           static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
+        // 129+ queries: the tile on 16 x 16 x 64 MFMAs, unless the shard is so large that its epilogue's 32-bit word offsets
+        // inside a pair of count planes would not do (then the 32 x 32 x 32 form).  Measured on one box, eight-wave form long
+        // gone: 1M x 3072 rows x 256 queries 0.89 -> 0.85 ms, x 1024: 3.23 -> 2.92 ms; C3 (4 launches) 2.23 -> 2.13 ms each.
+        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30);
+        if (tile16 && B > 256) ORR_LAUNCH_I8W16(false);
+        else if (tile16 && B > 128) ORR_LAUNCH_I8W16(true);
+        else if (B > 256) ORR_LAUNCH_I8W4(8, false);
         else if (B > 128) ORR_LAUNCH_I8W4(8, true);
         else ORR_LAUNCH_I8W4(4, true);
+#undef ORR_LAUNCH_I8W16
     }
     else if (B > 128) ORR_LAUNCH_I8(8);
     else if (B > 64) ORR_LAUNCH_I8(4);
