@@ -160,9 +160,6 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
     }
     if (st) { asm volatile("" :: "v"(cj[0]), "v"(rb[0]), "v"(eb[0])); ORR_EPI_STAMP(4); }
     int parked = 0;
-#ifdef ORR_X_COUNT1B
-    int n_flagged = 0;
-#endif
     // the query constants of (block i, element e) for this lane: {0.7/sqrt(normA) [* s1], floor - margin, 0.2/terms, int8: query part of the bound}
     auto qf_of = [&](int i, int e) -> float4 {
         const int qi = qbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -221,9 +218,6 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
                 if (i == 0) { ORR_EPI_STAMP(5); }
                 continue;
             }
-#ifdef ORR_X_COUNT1B
-            ++n_flagged;
-#endif
         }
         // Pass 1b: the same tests element by element, parking what passes.  With staged inputs it only runs for a block in
         // which 1a found something (about one block in fifteen on the bench corpus).
@@ -265,9 +259,6 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
         if (i == 0) { ORR_EPI_STAMP(5); }
     }
     ORR_EPI_STAMP(6);
-#ifdef ORR_X_COUNT1B
-    if (st && lane == 0) st[7] = (unsigned long long)n_flagged;
-#endif
 #undef ORR_EPI_STAMP
     if (parked > QDEPTH) parked = QDEPTH;
     for (int s = 0; s < parked; ++s) {
@@ -472,9 +463,6 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
         any_of[b] = wave_any;
         if constexpr (b == 0) { ORR_EPI_STAMP(5); }
     });
-#ifdef ORR_X_COUNT1B
-    if (st && lane == 0) st[7] = __builtin_amdgcn_s_memtime();
-#endif
     int token_1b = acc_token;
     asm volatile("" : "+v"(token_1b));            // (its own token: pass 1b reads the accumulators again instead of keeping 1a's 256 values)
     static_for<4>([&](auto b_c) {
