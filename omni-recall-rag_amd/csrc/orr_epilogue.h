@@ -291,12 +291,21 @@ __device__ __forceinline__ void fused_epilogue(const ACC (&acc)[NI][NJ], int qba
 
 // ---------------------------------------------------------------------------
 // The same epilogue for 16 x 16 accumulator tiles (v_mfma_i32_16x16x64_i8; the int8 screening GEMM's 128 x 128 wave tile as
-// 8 x 8 tiles of four registers).  Element e of lane (c = lane & 15, g = lane >> 4) of tile (i, j) belongs to query
+// 8 x 8 tiles of four registers).  Element e of lane (c, g; tile16_c_of, tile16_g_of below) of tile (i, j) belongs to query
 // qbase + 16 i + 4 g + e and to row colbase + 16 j + c: a lane holds 8 rows x 32 queries (the 32 x 32 form: 4 x 64).
 // A block of 32 queries is the tile pair (2 b, 2 b + 1); within it the lane's queries are 16 t + 4 g + e (t = 0, 1), whose
 // counts sit in count word 2 t + (g >> 1) at nibble 4 (g & 1) + e -- so a lane needs two of a row's four words per block,
 // shifted by 16 (g & 1) once, and the nibble index is the compile-time e.  Everything else is fused_epilogue's.
 // ---------------------------------------------------------------------------
+// Which 16 rows a fragment holds: fragment row m of a 16-row tile is the tile's row tile16_row(m) -- the row quads 1 and 3
+// change places.  With the stored swizzle (chunk c of row r in slot c ^ ((r >> 2) & 3), made for 32-row fragments) the
+// straight order puts rows m and m + 4 of a ds_read_b128 lane group on the same banks (2-way: half of the LDS array's cycles
+// by the counters); in this order every group covers the 64 banks once.  Queries and rows are read the same way, so
+// accumulator element e of lane (c, g) belongs to query 16 i + 4 ((-g) & 3) + e and row 16 j + tile16_row(c).
+__device__ __forceinline__ int tile16_row(int m) { return (((0 - (m >> 2)) & 3) << 2) | (m & 3); }
+__device__ __forceinline__ int tile16_c_of(int lane) { return tile16_row(lane & 15); }
+__device__ __forceinline__ int tile16_g_of(int lane) { return (0 - (lane >> 4)) & 3; }
+
 struct EpiTileLoads16 {
     double2 rc[8];
     float4 rf[8];
@@ -308,7 +317,7 @@ struct EpiTileLoads16 {
 __device__ __forceinline__ void epilogue_word_offsets16(uint32_t (&at)[8], int64_t colbase, int32_t B, int64_t n_rows, const FusedEpilogue &epi,
                                                         int lane)
 {
-    const int c = lane & 15, g = lane >> 4;
+    const int c = tile16_c_of(lane), g = tile16_g_of(lane);
     const int32_t n_qg = (B + 31) >> 5;
     const uint32_t plane_dist = epi.count_planes ? (uint32_t)((int64_t)n_qg * epi.plane_stride) : 0u;
 #pragma unroll
@@ -342,7 +351,7 @@ __device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const
 __device__ __forceinline__ void epilogue_issue_loads16(EpiTileLoads16 &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                        const FusedEpilogue &epi, int lane)
 {
-    const int c = lane & 15;
+    const int c = tile16_c_of(lane);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int64_t col = colbase + j * 16 + c;
@@ -413,7 +422,7 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
                                                  HOOK between_blocks = HOOK())
 {
 #define ORR_EPI_STAMP(k) if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime()
-    const int c = lane & 15, g = lane >> 4;
+    const int c = tile16_c_of(lane), g = tile16_g_of(lane);
     const int sh = 16 * (g & 1);
     float rb[8], cj[8], eb[8];
     const int64_t col0 = colbase + c;                                      // this lane's row of row tile 0 (tile j: + 16 j)

@@ -622,8 +622,8 @@ __global__ __launch_bounds__(256, 1) void screen_tile4_kernel(const __bf16 *__re
 // requests, barrier protocol, tail, refill and epilogue inputs as screen_tile4_kernel; the 128 x 128 wave tile is 8 x 8
 // accumulator tiles of four registers.  Why: tools/mfma_rate.hip -- with every matrix core busy the chip holds 1.88 GHz on
 // this shape against 1.60 GHz on 32 x 32 x 32 at the same operations per cycle (profiles/r02_mfma_rate_microbench.txt).
-// The stored swizzle was made for 32-row fragments: a 16-row x 4-chunk fragment read is a 2-way bank conflict (LDS
-// cycles, which this kernel has to spare).  The epilogue for this accumulator layout: fused_epilogue16 (orr_epilogue.h).
+// The stored swizzle was made for 32-row fragments; a fragment here takes its 16 rows in the order tile16_row, which makes
+// the 16-row x 4-chunk reads conflict-free on it.  The epilogue for this accumulator layout: fused_epilogue16 (orr_epilogue.h).
 // ---------------------------------------------------------------------------
 template <bool NT>
 __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
@@ -688,6 +688,10 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
 #define ORR_STAMP(k) if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + (k)] = __builtin_amdgcn_s_memtime()
     for (int id = valid_from(blockIdx.x); id < total_ids;) {
     ORR_STAMP(0);
+    // (laundered per output tile: what hangs on the lane number -- fragment offsets, the epilogue's row and query numbers --
+    // is made again for every tile instead of living, spilled, across the epilogue)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
     const int next_id = valid_from(id + gridDim.x);
     const bool has_next = next_id < total_ids;
     const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
@@ -695,15 +699,16 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     const int b0 = mt * kScBM;
 
     // the accumulators: a[0:255], tile (query tile i, row tile j) = a[4 (8 i + j) .. + 3] -- no C++ object, see the K loop
-    // (zeroed right in front of the first K-tile, so that no compiler-made code runs between the two)
+    // (never zeroed: the first K-tile's MFMAs multiply onto the constant 0)
     int acc_token = 0;
     int c_a = ring_a, c_b = ring_b;                                         // ring stages of the K-tile whose fragments are read next
     // 16 x 16 x 64 fragments: lane = (row l & 15, 16-byte chunk l >> 4 of the row's 64 bytes = the whole K-tile); the stored
     // slot of chunk c in row r is c ^ ((r >> 2) & 3), and (r >> 2) & 3 = (l >> 2) & 3 for every tile of 16 rows
-    const int fo = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4);
+    // -- read for the fragment rows in the order tile16_row (orr_epilogue.h), which is what makes the reads conflict-free
+    const int frow = tile16_row(lane_t & 15);
+    const int fo = frow * 64 + (((lane_t >> 4) ^ ((frow >> 2) & 3)) << 4);
     auto a_at = [&]() { return lds_a + c_a * kScImage + wr * 128 * 64 + fo; };
     auto b_at = [&]() { return lds_b + c_b * kScImage + wc * 128 * 64 + fo; };
-    auto next_stage = [&]() { c_a = c_a + 1 == kS4NA ? 0 : c_a + 1; c_b = c_b + 1 == kS4NB ? 0 : c_b + 1; };
     // 64 MFMAs per K-tile (16.3 cycles each), 16 fragment reads, 8 requests.  First half: query tiles 0..3 against all
     // eight row tiles (row tile varies fastest), the fragments of query tiles 4..7 arriving meanwhile; the barrier; second
     // half column by column (row tile j against query tiles 4..7), so that row fragment j is free after its column and is
@@ -715,8 +720,9 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     // and 61 s_nop per K-tile); with one asm statement per MFMA the allocator moved tiles between code regions right behind
     // MFMAs whose latency it cannot see (wrong results) or kept copies in vector registers (1,062 spills).  Hazards the text
     // has to respect itself: a fragment register is overwritten at the earliest 4 MFMAs after its last use (plus the LDS
-    // latency), every fragment read is waited for (lgkmcnt(0) in the middle and at the end) before the half that uses it, and
-    // the accumulators are not read before the s_nops behind the K loop.
+    // latency), every fragment read is waited for (counted lgkmcnt) before the half that uses it, and the accumulators are
+    // not read before the s_nops behind the K loop.  The K-tile's bookkeeping (ring stages, fragment addresses, request
+    // offsets) is part of the text too, in the shadow of the MFMAs: the loop around it is a counter and a branch.
 #define ORR_SB __builtin_amdgcn_sched_barrier(0)
 #define ORR_RD(dst, p, i) dst = *reinterpret_cast<const i32x4v *>((p) + (i) * 1024); ORR_SB
     // The epilogue's one trip to global memory (this thread's query constants for the LDS copy, its rows' constants and
@@ -736,7 +742,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
             const int q = b0 + tid;
             qf_mine = load_global(ep.qf, (uint32_t)(q < B ? q : B - 1));
-            epilogue_issue_loads16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane);
+            epilogue_issue_loads16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);
         }
     };
     auto refill = [&](auto role) __attribute__((always_inline)) {          // every stage of this wave's ring requested
@@ -761,46 +767,69 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
         ORR_RD(fb4, pb, 4); ORR_RD(fb5, pb, 5); ORR_RD(fb6, pb, 6); ORR_RD(fb7, pb, 7);
         fa4 = fa5 = fa6 = fa7 = fa0;                                           // (defined; read in the first K-tile's first half)
     }
+    // The compiler's own wait for these reads has to land HERE: it does not see the waits inside the assembler text, and with
+    // the reads still pending in its books at the loop's entry it puts an s_waitcnt lgkmcnt(0) in front of every K-tile.
+    asm volatile("" : "+v"(fa0), "+v"(fa1), "+v"(fa2), "+v"(fa3), "+v"(fb0), "+v"(fb1), "+v"(fb2), "+v"(fb3),
+                      "+v"(fb4), "+v"(fb5), "+v"(fb6), "+v"(fb7));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile(ORR_T16_ZERO ::: ORR_T16_ACC_CLOBBERS);
-    // one K-tile.  REQ: its stages are re-requested (K-tile t + RING of this output tile); WAITN: what may stay in flight
-    // when this wave's pieces of K-tile t + 1 have landed; HOOK: the epilogue's requests go out in front of it
-    auto tile_iter = [&](auto req_c, auto waitn_c, auto hook_c) __attribute__((always_inline)) {
-        constexpr bool REQ = decltype(req_c)::value, HOOK = decltype(hook_c)::value;
+    // The state the K-tiles' text keeps for itself (tools/gen_tile16_asm.py: ring stages, LDS addresses, request offsets, in
+    // vector registers -- as compiler-made code between the texts, twenty dependent scalar instructions, it cost 230 idle
+    // cycles per K-tile):
+    const uint32_t pab = (uint32_t)(uintptr_t)lds_a + (uint32_t)(wr * 128 * 64 + fo), pbb = (uint32_t)(uintptr_t)lds_b + (uint32_t)(wc * 128 * 64 + fo);
+    uint32_t pa = pab + (uint32_t)c_a * kScImage, pan = pab + (uint32_t)(c_a + 1 == kS4NA ? 0 : c_a + 1) * kScImage;
+    uint32_t pbn = pbb + (uint32_t)(c_b + 1 == kS4NB ? 0 : c_b + 1) * kScImage, pat = 0, pbt = 0;
+    const uint32_t pae = pab + (uint32_t)kS4NA * kScImage, pbe = pbb + (uint32_t)kS4NB * kScImage;
+    const uint32_t m0e = ring_lds + (uint32_t)RING * kScImage;
+    uint32_t m0s = ring_lds, m0v = ring_lds + (uint32_t)(s_stage == 0 ? RING - 1 : s_stage - 1) * kScImage;    // (advanced in front of the requests)
+    asm volatile("" : "+v"(m0s), "+v"(m0v));                                                           // (vector registers, the same in every lane)
+    uint32_t vo = lane_off - (uint32_t)kScImage, vo2 = vo + 4096u;                                    // (likewise)
+    const uint64_t src = (uint64_t)(uintptr_t)s_src;
+    const int n_main = T - RING;
+    // one K-tile.  FIRST: it multiplies onto 0 (no zeroing of the accumulators); REQ: its stages are re-requested (K-tile
+    // t + RING of this output tile); WAITN: what may stay in flight when this wave's pieces of K-tile t + 1 have landed;
+    // HOOK: the epilogue's requests go out in front of it
+    auto tile_iter = [&](auto first_c, auto req_c, auto waitn_c, auto hook_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value, REQ = decltype(req_c)::value, HOOK = decltype(hook_c)::value;
         constexpr int WAITN = decltype(waitn_c)::value;
         if constexpr (HOOK) epilogue_requests();
-        const uint32_t pa = (uint32_t)(uintptr_t)a_at();                     // query fragments 4..7 of this K-tile
-        next_stage();
-        const uint32_t pan = (uint32_t)(uintptr_t)a_at(), pbn = (uint32_t)(uintptr_t)b_at();   // the next K-tile's fragments (read behind the barrier)
-        const uint32_t m0a = ring_lds + (uint32_t)s_stage * kScImage, m0b = m0a + 4096u;
-        const uint64_t srca = (uint64_t)(uintptr_t)s_src, srcb = srca + 4096u;
+        uint32_t m0_scratch;
 #define ORR_T16_OPERANDS \
             : "+{v[192:195]}"(fa0), "+{v[196:199]}"(fa1), "+{v[200:203]}"(fa2), "+{v[204:207]}"(fa3), \
               "+{v[208:211]}"(fa4), "+{v[212:215]}"(fa5), "+{v[216:219]}"(fa6), "+{v[220:223]}"(fa7), \
               "+{v[224:227]}"(fb0), "+{v[228:231]}"(fb1), "+{v[232:235]}"(fb2), "+{v[236:239]}"(fb3), \
-              "+{v[240:243]}"(fb4), "+{v[244:247]}"(fb5), "+{v[248:251]}"(fb6), "+{v[252:255]}"(fb7) \
-            : [pa] "v"(pa), [pan] "v"(pan), [pbn] "v"(pbn), [lo] "v"(lane_off), [m0a] "s"(m0a), [m0b] "s"(m0b), [srca] "s"(srca), \
-              [srcb] "s"(srcb), [wn] "n"(WAITN) \
-            : ORR_T16_ACC_CLOBBERS, "memory"
-        if constexpr (!REQ) asm volatile(ORR_T16_KTILE_NOREQ ORR_T16_OPERANDS);
-        else if constexpr (NT && ROWS) asm volatile(ORR_T16_KTILE_REQ_NT ORR_T16_OPERANDS);
-        else asm volatile(ORR_T16_KTILE_REQ ORR_T16_OPERANDS);
-#undef ORR_T16_OPERANDS
-        if constexpr (REQ) {                                                 // (inside an output tile: no crossing to look for)
-            s_stage = s_stage + 1 == RING ? 0 : s_stage + 1;
-            ++s_k;
-            s_src += kScImage;
+              "+{v[240:243]}"(fb4), "+{v[244:247]}"(fb5), "+{v[248:251]}"(fb6), "+{v[252:255]}"(fb7), \
+              [pa] "+v"(pa), [pan] "+v"(pan), [pbn] "+v"(pbn), [pat] "+v"(pat), [pbt] "+v"(pbt), [vo] "+v"(vo), [vo2] "+v"(vo2), [m0v] "+v"(m0v), [st] "=&s"(m0_scratch) \
+            : [pab] "v"(pab), [pbb] "v"(pbb), [pae] "v"(pae), [pbe] "v"(pbe), [m0s] "v"(m0s), [src] "s"(src), [m0e] "s"(m0e), [wn] "n"(WAITN) \
+            : ORR_T16_ACC_CLOBBERS, "vcc", "scc", "memory"
+        if constexpr (FIRST) {
+            if constexpr (!REQ) asm volatile(ORR_T16_KTILE_FIRST_NOREQ ORR_T16_OPERANDS);
+            else if constexpr (NT && ROWS) asm volatile(ORR_T16_KTILE_FIRST_REQ_NT ORR_T16_OPERANDS);
+            else asm volatile(ORR_T16_KTILE_FIRST_REQ ORR_T16_OPERANDS);
+        } else {
+            if constexpr (!REQ) asm volatile(ORR_T16_KTILE_NOREQ ORR_T16_OPERANDS);
+            else if constexpr (NT && ROWS) asm volatile(ORR_T16_KTILE_REQ_NT ORR_T16_OPERANDS);
+            else asm volatile(ORR_T16_KTILE_REQ ORR_T16_OPERANDS);
         }
+#undef ORR_T16_OPERANDS
     };
-    for (int t = 0; t < T - RING; ++t)
-        tile_iter(std::true_type{}, std::integral_constant<int, KP * (RING - 2)>{}, std::false_type{});
+    using WaitMain = std::integral_constant<int, KP * (RING - 2)>;
+    {                                                                      // (n_main >= 1: the launcher sends D / 64 <= kS4NB elsewhere)
+        tile_iter(std::true_type{}, std::true_type{}, WaitMain{}, std::false_type{});
+        for (int t = 1; t < n_main; ++t) {
+            tile_iter(std::false_type{}, std::true_type{}, WaitMain{}, std::false_type{});
+        }
+        s_stage = (s_stage + n_main) % RING;                               // (inside an output tile: no crossing to look for)
+        s_k += n_main;
+        s_src += (int64_t)n_main * kScImage;
+    }
     ORR_STAMP(7);
     // the last RING K-tiles: r-th of them leaves RING - 2 - r tiles in flight (the last one waits for nothing: 63)
     auto tail = [&](auto self, auto r_c) __attribute__((always_inline)) {
         constexpr int r = decltype(r_c)::value;
         if constexpr (r < RING) {
-            tile_iter(std::false_type{}, std::integral_constant<int, (r <= RING - 2 ? KP * (RING - 2 - r) : 63)>{},
-                      std::integral_constant<bool, r == RING - 2>{});
+            using WaitTail = std::integral_constant<int, (r <= RING - 2 ? KP * (RING - 2 - r) : 63)>;
+            using Hook = std::integral_constant<bool, r == RING - 2>;
+            tile_iter(std::false_type{}, std::false_type{}, WaitTail{}, Hook{});
             self(self, std::integral_constant<int, r + 1>{});
         }
     };
@@ -827,7 +856,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             asm volatile("" : "+v"(pre.rf[j].x), "+v"(pre.rf[j].y), "+v"(pre.rf[j].z), "+v"(pre.rf[j].w));
             asm volatile("" : "+v"(pre.w[0][j][0]), "+v"(pre.w[0][j][1]));
         }
-        epilogue_issue_later_words16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane);    // (they land under the first block's tests)
+        epilogue_issue_later_words16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);    // (they land under the first block's tests)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (bare: __syncthreads() would also wait for outstanding requests)
         unsigned long long *st = (epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
         // the ring refill for the next output tile rides on the epilogue: a quarter of this wave's requests in front of each
@@ -845,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             };
             if (row_loader) part(std::true_type{}); else part(std::false_type{});
         };
-        fused_epilogue16<kS4Queue>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
+        fused_epilogue16<kS4Queue>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
     }
 #undef ORR_RD
 #undef ORR_SB
@@ -1308,6 +1337,9 @@ static int64_t screen_grid(int64_t tiles, int32_t k_tiles)
     static const int64_t per_launch = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return (int64_t)0;
+        // ORR_SCREEN_GRID=n (diagnostic): n persistent workgroups instead of one per CU -- how the K loop's cycles depend on how
+        // many CUs multiply at once
+        if (const char *g = getenv("ORR_SCREEN_GRID")) { const int n = atoi(g); if (n >= 8 && n <= cus) return (int64_t)(n / 8 * 8); }
         return (int64_t)(cus / 8 * 8);
     }();
     return per_launch > 0 && tiles > per_launch ? per_launch : tiles;
@@ -1373,7 +1405,7 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
         // 129+ queries: the tile on 16 x 16 x 64 MFMAs, unless the shard is so large that its epilogue's 32-bit word offsets
         // inside a pair of count planes would not do (then the 32 x 32 x 32 form).  Measured on one box, eight-wave form long
         // gone: 1M x 3072 rows x 256 queries 0.89 -> 0.85 ms, x 1024: 3.23 -> 2.92 ms; C3 (4 launches) 2.23 -> 2.13 ms each.
-        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30);
+        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30) && D / 64 > kS4NB;
         if (tile16 && B > 256) ORR_LAUNCH_I8W16(false);
         else if (tile16 && B > 128) ORR_LAUNCH_I8W16(true);
         else if (B > 256) ORR_LAUNCH_I8W4(8, false);

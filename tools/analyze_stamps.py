@@ -45,3 +45,16 @@ if v7.any():
 # the first tile of a workgroup includes the cold prologue
 seq_k = [(s1 - s0)[:, t][valid[:, t]] for t in range(min(6, valid.shape[1]))]
 print("K loop by tile sequence:", [int(np.median(x)) for x in seq_k if x.size])
+# real time (s_memrealtime, 100 MHz): when the workgroups began and ended relative to the first one
+last = np.array([np.flatnonzero(v)[-1] if v.any() else 0 for v in valid])
+wg = np.flatnonzero(valid.any(axis=1))
+clk_med = float(np.median(clk))
+t_begin = np.array([rt[w, first_i] - (s2[w, first_i] - s0[w, first_i]) / clk_med * 100e6
+                    for w, first_i in zip(wg, [np.flatnonzero(valid[w])[0] for w in wg])])
+t_end = np.array([rt[w, last[w]] for w in wg]).astype(np.float64)
+t0 = t_begin.min()
+print("real time, us from the first workgroup's first tile: begins median %.1f p90 %.1f max %.1f; ends min %.1f median %.1f max %.1f" %
+      tuple(x / 100.0 for x in (np.median(t_begin - t0), np.percentile(t_begin - t0, 90), (t_begin - t0).max(),
+                                (t_end - t0).min(), np.median(t_end - t0), (t_end - t0).max())))
+tiles_of = valid.sum(axis=1)[wg]
+print("tiles per workgroup: min %d median %d max %d" % (tiles_of.min(), np.median(tiles_of), tiles_of.max()))
