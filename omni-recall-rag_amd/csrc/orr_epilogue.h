@@ -439,7 +439,10 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
     // Pass 1a for all four blocks first, pass 1b (rare, and twenty times the code) for the flagged blocks behind them: with
     // 1b's code between the blocks' 1a, every block began with a jump over 21 KiB and a cold instruction cache (6,500 cycles
     // per output tile by the stamps; the accumulators stay where they are, so 1b can read them again later).
-    unsigned long long any_of[4];
+    // What 1a hands to 1b: one bit per (block, group of 8 rows x one query per lane) -- 1b then runs for the flagged GROUPS only
+    // (a flagged block is nearly always one element: with the whole block re-tested, 256 tests per lane, the wave that had it
+    // came 10,000 cycles late to the next barrier, and two tiles in three have such a wave).
+    uint32_t group_flags = 0u;
     static_for<4>([&](auto b_c) {
         constexpr int b = decltype(b_c)::value;
         between_blocks(b);
@@ -447,7 +450,6 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
 #pragma unroll
         for (int j = 0; j < 8; ++j) { w[j][0] = L.w[b][j][0] >> sh; w[j][1] = L.w[b][j][1] >> sh; }
         // Pass 1a, branch-free (see fused_epilogue): could any of the block's 8 x 8 elements of any lane reach its query's floor?
-        unsigned long long wave_any = 0ull;
         float4 qf = qf_lane[32 * b];
         static_for<8>([&](auto te_c) {
             constexpr int te = decltype(te_c)::value, t = te >> 2, e = te & 3;
@@ -461,29 +463,32 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
                 const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
                 hit[j] = __builtin_amdgcn_ballot_w64(!(upper < qf.y));
             });
+            unsigned long long group_any = hit[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wave_any |= hit[j];
+            for (int j = 1; j < 8; ++j) group_any |= hit[j];
+            group_flags |= group_any != 0ull ? 1u << (8 * b + te) : 0u;
             // (pinned: the flags are only looked at behind all four blocks, and left alone the compiler postpones the ORs to
             // there -- parking all 256 masks in vector-register lanes meanwhile and fetching them back one v_readlane at a
             // time, 7,000 cycles per tile)
-            asm volatile("" : "+s"(wave_any));
+            asm volatile("" :: "s"(group_flags));
             qf = qf_next;
         });
-        any_of[b] = wave_any;
         if constexpr (b == 0) { ORR_EPI_STAMP(5); }
     });
     int token_1b = acc_token;
     asm volatile("" : "+v"(token_1b));            // (its own token: pass 1b reads the accumulators again instead of keeping 1a's 256 values)
     static_for<4>([&](auto b_c) {
         constexpr int b = decltype(b_c)::value;
-        if (any_of[b] != 0ull) {
-            // Pass 1b: the same tests element by element, parking what passes (about one block in fifteen).  Its count words
-            // come from memory again: kept in registers since pass 1a they were 64 more live values for a rare path.
+        if (((group_flags >> (8 * b)) & 0xffu) != 0u) {
+            // Pass 1b: the same tests element by element, parking what passes (about one block in fifteen, one group of it).
+            // Its count words come from memory again: kept in registers since pass 1a they were 64 more live values for a rare
+            // path.
             uint32_t at1[8], w1[8][2];
             epilogue_word_offsets16(at1, colbase, B, n_rows, epi, lane);
             epilogue_load_words16(w1, at1, b, qbase, B, epi);
             static_for<8>([&](auto te_c) {
                 constexpr int te = decltype(te_c)::value, t = te >> 2, e = te & 3, i = 2 * b + t;
+                if ((group_flags & (1u << (8 * b + te))) == 0u) return;
                 const int qi = qbase + 16 * i + 4 * g + e;
                 const float4 q1 = qf_lane[32 * b + 16 * t + e];
                 const bool has_query = qi < B;

@@ -818,9 +818,12 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
         for (int t = 1; t < n_main; ++t) {
             tile_iter(std::false_type{}, std::true_type{}, WaitMain{}, std::false_type{});
         }
-        s_stage = (s_stage + n_main) % RING;                               // (inside an output tile: no crossing to look for)
-        s_k += n_main;
-        s_src += (int64_t)n_main * kScImage;
+        s_stage = (s_stage + n_main) % RING;
+        // every K-tile of this output tile is requested now: the stream moves on to the workgroup's next one (the refill
+        // behind the epilogue starts there)
+        const int nid = valid_from(s_id + gridDim.x);
+        if (nid < total_ids) { s_id = nid; s_k = 0; s_src = stream_src(nid); }
+        else { s_k = T; s_src += (int64_t)n_main * kScImage; }
     }
     ORR_STAMP(7);
     // the last RING K-tiles: r-th of them leaves RING - 2 - r tiles in flight (the last one waits for nothing: 63)
@@ -1334,14 +1337,16 @@ __global__ __launch_bounds__(256) void i8_tile_queries_kernel(const int8_t *__re
 static int64_t screen_grid(int64_t tiles, int32_t k_tiles)
 {
     if (k_tiles < kScNB) return tiles;        // the requests of a tile reach kScNB K-tiles ahead: never past the next output tile
-    static const int64_t per_launch = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) return (int64_t)0;
-        // ORR_SCREEN_GRID=n (diagnostic): n persistent workgroups instead of one per CU -- how the K loop's cycles depend on how
-        // many CUs multiply at once
-        if (const char *g = getenv("ORR_SCREEN_GRID")) { const int n = atoi(g); if (n >= 8 && n <= cus) return (int64_t)(n / 8 * 8); }
-        return (int64_t)(cus / 8 * 8);
+    static const int64_t cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return (int64_t)0;
+        return (int64_t)(n / 8 * 8);
     }();
+    int64_t per_launch = cus;
+    // ORR_SCREEN_GRID=n (diagnostic, read at every launch): n persistent workgroups instead of one per CU -- how the K loop's
+    // cycles depend on how many CUs multiply at once, and the test that results do not depend on which
+    // workgroup gets which output tiles
+    if (const char *g = getenv("ORR_SCREEN_GRID")) { const int n = atoi(g); if (n >= 8 && n <= cus) per_launch = n / 8 * 8; }
     return per_launch > 0 && tiles > per_launch ? per_launch : tiles;
 }
 

@@ -3,6 +3,8 @@ oracle on the same inputs.  Bar: identical row ids in identical order, fp64 scor
 bit-identical (the survivors are finished in the reference's own arithmetic)."""
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -850,10 +852,6 @@ def test_four_wave_screening_kernel_variants_match_oracle():
     created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
     words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "rollout"])
     contents = [" ".join(w).encode() for w in words[rng.integers(0, len(words), (n, 4))]]
-    idx = P.RecallIndex(dim=dim)
-    for r0 in range(0, n, 50_000):
-        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], contents[r0:r0 + 50_000])
-    idx.seal()
     B = 300
     qs = rng.standard_normal((B, dim)).astype(np.float32)
     qs[0] = emb[5]
@@ -864,10 +862,23 @@ def test_four_wave_screening_kernel_variants_match_oracle():
     qs[129] = emb[77_777] * np.float32(3.0)
     qs[257] = emb[n - 70]
     qs[299] = emb[123]
+    # rows whose whole similarity to a query sits in ONE K-tile (the last 64 dimensions, the first 64), in output tiles that are
+    # not a workgroup's first: a stream that hands a K-tile of the neighbouring output tile to the K loop loses exactly them
+    qs[5] = 0.0
+    qs[5, dim - 64:] = rng.standard_normal(64).astype(np.float32)
+    qs[6] = 0.0
+    qs[6, :64] = rng.standard_normal(64).astype(np.float32)
+    for r in (70_001, 150_003, 199_990):
+        emb[r] = np.float32(0.01) * emb[r] + np.float32(2.0) * qs[5]
+        emb[r + 5] = np.float32(0.01) * emb[r + 5] + np.float32(3.0) * qs[6]
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], contents[r0:r0 + 50_000])
+    idx.seal()
     texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] if b % 3 else "" for b in range(B)]
     terms = [P.text.query_terms(t) if t else [] for t in texts]
     corpus = orc.OracleCorpus(emb, created, contents)
-    check = {0, 1, 2, 3, 64, 65, 69, 127, 129, 199, 255, 256, 257, 299}
+    check = {0, 1, 2, 3, 5, 6, 64, 65, 69, 127, 129, 199, 255, 256, 257, 299}
     for nb in (70, 128, 130, 256, 300):
         idx.set_profiling(True)
         idx.reset_search_stats()
@@ -881,6 +892,24 @@ def test_four_wave_screening_kernel_variants_match_oracle():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow), (nb, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (nb, b)
+    # which workgroup gets which output tiles must not show: the same survivors, pair for pair, with 8 and with 64 persistent
+    # workgroups as with one per CU (ORR_SCREEN_GRID is read at every launch)
+    def run_with_grid(g):
+        if g is None:
+            os.environ.pop("ORR_SCREEN_GRID", None)
+        else:
+            os.environ["ORR_SCREEN_GRID"] = str(g)
+        try:
+            idx.reset_search_stats()
+            out = idx.search(qs[:256], terms[:256], NOW, 10, candidate_limit=n)
+            return out, idx.search_stats()["survivors_total"]
+        finally:
+            os.environ.pop("ORR_SCREEN_GRID", None)
+    (r_a, s_a, c_a), surv_a = run_with_grid(None)
+    for g in (8, 64):
+        (r_g, s_g, c_g), surv_g = run_with_grid(g)
+        assert surv_g == surv_a, (g, surv_g, surv_a)
+        assert np.array_equal(c_g, c_a) and np.array_equal(r_g, r_a) and np.array_equal(s_g, s_a), g
     # the same answers with the two-stage pass switched off (exact kernels only)
     idx.set_option("two_stage", 0)
     rows0, scores0, counts0 = idx.search(qs[:130], terms[:130], NOW, 10, candidate_limit=n)
