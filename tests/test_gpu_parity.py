@@ -892,6 +892,14 @@ def test_four_wave_screening_kernel_variants_match_oracle():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow), (nb, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (nb, b)
+    # the same two queries through the kernels for small batches (one-query stream, 2..4, 5..64 queries)
+    for nb in (1, 2, 4, 8, 33, 64):
+        sel = ([5, 6] + list(range(7, 7 + nb)))[:nb]
+        rows_s, scores_s, counts_s = idx.search(qs[sel], [terms[b] for b in sel], NOW, 10, candidate_limit=n)
+        for pos, b in enumerate(sel[:2]):
+            orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
+            assert list(rows_s[pos, :counts_s[pos]]) == list(orow), (nb, b)
+            assert np.array_equal(scores_s[pos, :counts_s[pos]], osc), (nb, b)
     # which workgroup gets which output tiles must not show: the same survivors, pair for pair, with 8 and with 64 persistent
     # workgroups as with one per CU (ORR_SCREEN_GRID is read at every launch)
     def run_with_grid(g):
