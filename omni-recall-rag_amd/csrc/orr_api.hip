@@ -1823,7 +1823,10 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
                 if (prefix_i8 && two_stage && n >= (int64_t)2000000) {
                     n_ranges = 4;
-                    for (int r = 1; r < 4; ++r) range_row[r] = (n * r / 4) / 256 * 256;
+                    // (boundaries on whole rounds of the persistent GEMM -- 256 workgroups x 256-row tiles: every workgroup of a
+                    // launch then multiplies the same number of tiles; only the last range ends on a partial round)
+                    constexpr int64_t kRound = 256 * 256;
+                    for (int r = 1; r < 4; ++r) range_row[r] = (n * r / 4 + kRound / 2) / kRound * kRound;
                 }
                 Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[1] - range_row[0]));
                 HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, 0, range_row[1]));

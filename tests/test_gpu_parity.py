@@ -902,22 +902,23 @@ def test_four_wave_screening_kernel_variants_match_oracle():
             assert np.array_equal(scores_s[pos, :counts_s[pos]], osc), (nb, b)
     # which workgroup gets which output tiles must not show: the same survivors, pair for pair, with 8 and with 64 persistent
     # workgroups as with one per CU (ORR_SCREEN_GRID is read at every launch)
-    def run_with_grid(g):
+    def run_with_grid(g, nbq):
         if g is None:
             os.environ.pop("ORR_SCREEN_GRID", None)
         else:
             os.environ["ORR_SCREEN_GRID"] = str(g)
         try:
             idx.reset_search_stats()
-            out = idx.search(qs[:256], terms[:256], NOW, 10, candidate_limit=n)
+            out = idx.search(qs[:nbq], terms[:nbq], NOW, 10, candidate_limit=n)
             return out, idx.search_stats()["survivors_total"]
         finally:
             os.environ.pop("ORR_SCREEN_GRID", None)
-    (r_a, s_a, c_a), surv_a = run_with_grid(None)
-    for g in (8, 64):
-        (r_g, s_g, c_g), surv_g = run_with_grid(g)
-        assert surv_g == surv_a, (g, surv_g, surv_a)
-        assert np.array_equal(c_g, c_a) and np.array_equal(r_g, r_a) and np.array_equal(s_g, s_a), g
+    for nbq in (64, 128, 256):                                            # eight-wave form, four-wave form, 16 x 16 x 64 form
+        (r_a, s_a, c_a), surv_a = run_with_grid(None, nbq)
+        for g in (8, 64):
+            (r_g, s_g, c_g), surv_g = run_with_grid(g, nbq)
+            assert surv_g == surv_a, (nbq, g, surv_g, surv_a)
+            assert np.array_equal(c_g, c_a) and np.array_equal(r_g, r_a) and np.array_equal(s_g, s_a), (nbq, g)
     # the same answers with the two-stage pass switched off (exact kernels only)
     idx.set_option("two_stage", 0)
     rows0, scores0, counts0 = idx.search(qs[:130], terms[:130], NOW, 10, candidate_limit=n)
