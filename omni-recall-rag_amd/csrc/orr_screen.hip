@@ -791,7 +791,6 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     auto tile_iter = [&](auto first_c, auto req_c, auto waitn_c, auto hook_c) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value, REQ = decltype(req_c)::value, HOOK = decltype(hook_c)::value;
         constexpr int WAITN = decltype(waitn_c)::value;
-        if constexpr (HOOK) epilogue_requests();
         uint32_t m0_scratch;
 #define ORR_T16_OPERANDS \
             : "+{v[192:195]}"(fa0), "+{v[196:199]}"(fa1), "+{v[200:203]}"(fa2), "+{v[204:207]}"(fa3), \
@@ -801,7 +800,14 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
               [pa] "+v"(pa), [pan] "+v"(pan), [pbn] "+v"(pbn), [pat] "+v"(pat), [pbt] "+v"(pbt), [vo] "+v"(vo), [vo2] "+v"(vo2), [m0v] "+v"(m0v), [st] "=&s"(m0_scratch) \
             : [pab] "v"(pab), [pbb] "v"(pbb), [pae] "v"(pae), [pbe] "v"(pbe), [m0s] "v"(m0s), [src] "s"(src), [m0e] "s"(m0e), [wn] "n"(WAITN) \
             : ORR_T16_ACC_CLOBBERS, "vcc", "scc", "memory"
-        if constexpr (FIRST) {
+        if constexpr (HOOK) {
+            // the epilogue's loads go out BEHIND this K-tile's counted wait (a vmcnt(0) here: it would wait for them too, 2,000
+            // cycles with the matrix core idle), i.e. between the two halves of its text
+            static_assert(!REQ && !FIRST, "the hook rides on a K-tile of the tail");
+            asm volatile(ORR_T16_KTILE_NOREQ_H1 ORR_T16_OPERANDS);
+            epilogue_requests();
+            asm volatile(ORR_T16_KTILE_NOREQ_H2 ORR_T16_OPERANDS);
+        } else if constexpr (FIRST) {
             if constexpr (!REQ) asm volatile(ORR_T16_KTILE_FIRST_NOREQ ORR_T16_OPERANDS);
             else if constexpr (NT && ROWS) asm volatile(ORR_T16_KTILE_FIRST_REQ_NT ORR_T16_OPERANDS);
             else asm volatile(ORR_T16_KTILE_FIRST_REQ ORR_T16_OPERANDS);

@@ -892,6 +892,13 @@ def test_four_wave_screening_kernel_variants_match_oracle():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow), (nb, b)
             assert np.array_equal(scores[b, :counts[b]], osc), (nb, b)
+    # a deeper cut: the top 50 of unstructured queries, where the scores around the cut lie a hair apart -- any row the
+    # screening pass under-estimates by more than its margin is missing from such a list
+    rows50, scores50, counts50 = idx.search(qs[:256], terms[:256], NOW, 50, candidate_limit=n)
+    for b in (7, 100, 200, 255):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 50, candidate_limit=n, threads=8)
+        assert list(rows50[b, :counts50[b]]) == list(orow), b
+        assert np.array_equal(scores50[b, :counts50[b]], osc), b
     # the same two queries through the kernels for small batches (one-query stream, 2..4, 5..64 queries)
     for nb in (1, 2, 4, 8, 33, 64):
         sel = ([5, 6] + list(range(7, 7 + nb)))[:nb]

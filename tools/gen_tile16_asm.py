@@ -111,6 +111,12 @@ def main():
         for name, req, nt in (("REQ", True, False), ("REQ_NT", True, True), ("NOREQ", False, False)):
             f.write("#define ORR_T16_KTILE_%s \\\n    %s\n" % (name, c_string(k_tile(req, nt))))
             f.write("#define ORR_T16_KTILE_FIRST_%s \\\n    %s\n" % (name, c_string(k_tile(req, nt, True))))
+        # the same K-tile in two statements (up to and including the barrier / the rest): the epilogue's loads are requested
+        # between them -- behind the K-tile's counted wait, which would otherwise wait for them as well
+        lines = k_tile(False, False)
+        cut = lines.index("s_barrier") + 1
+        f.write("#define ORR_T16_KTILE_NOREQ_H1 \\\n    %s\n" % c_string(lines[:cut]))
+        f.write("#define ORR_T16_KTILE_NOREQ_H2 \\\n    %s\n" % c_string(lines[cut:]))
         f.write("#define ORR_T16_ACC_CLOBBERS " + ", ".join('"a%d"' % n for n in range(256)) + "\n")
     print("wrote", os.path.normpath(path))
 
