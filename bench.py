@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
     ap.add_argument("--no-legs", action="store_true", help="headline only: skip the C2 leg (one GPU) / the C4 legs (several)")
-    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-steps-in-flight measurement of the C2 leg")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-steps-in-flight measurements (headline and C2 leg: reported beside `value`, never as it)")
     ap.add_argument("--no-robustness-legs", action="store_true",
                     help="skip the two 1M-row legs on unfriendly data: a clustered corpus (64 centroids + 0.1 noise: thousands of "
                          "survivors per query) and a keyword-heavy one (2^18 Zipf-distributed tokens of mixed length, substring terms)")
@@ -498,7 +498,7 @@ def main():
         idx = build_shard(P, syn, torch, 0, rows, dim, rows, dev, args.set_option)
         setup_s["headline_corpus"] = time.perf_counter() - t0
         head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, 1), rows, rows, B, terms=not args.no_terms)
-        head = run_leg(head_leg, args, env, idx, None, syn)
+        head = run_leg(head_leg, args, env, idx, None, syn, overlap=not args.no_overlap_leg)
         n_total, front = rows, None
     else:
         rows = args.rows_per_gpu or 12_500_000
@@ -550,7 +550,7 @@ def main():
             "setup_s": {kk: round(v, 2) for kk, v in setup_s.items()},
             "total_s": round(time.perf_counter() - t_start, 2),
         }
-        for extra in ("rccl_ranks_seen", "collectives_per_step", "backend"):
+        for extra in ("rccl_ranks_seen", "collectives_per_step", "backend", "two_steps_in_flight"):
             if extra in head:
                 out[extra] = head[extra]
         if parity is not None:
