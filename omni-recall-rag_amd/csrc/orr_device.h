@@ -19,6 +19,15 @@ typedef float gf32x2 __attribute__((ext_vector_type(2)));
 typedef double gf64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 load_global(const float4 *p, uint32_t i) { const gf32x4 v = as_global(reinterpret_cast<const gf32x4 *>(p))[i]; return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float2 load_global(const float2 *p, uint32_t i) { const gf32x2 v = as_global(reinterpret_cast<const gf32x2 *>(p))[i]; return make_float2(v.x, v.y); }
+// The same from a wave-uniform base and a 32-bit BYTE offset per lane (the caller guarantees it fits): one load with a scalar
+// base and a vector offset, no 64-bit address arithmetic per lane.
+template <typename V>
+__device__ __forceinline__ V load_global_at(const void *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) V *>((const __attribute__((address_space(1))) char *)base + byte_off);
+}
+__device__ __forceinline__ float4 load_global_at_f4(const float4 *p, uint32_t byte_off) { const gf32x4 v = load_global_at<gf32x4>(p, byte_off); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ double2 load_global_at_d2(const double2 *p, uint32_t byte_off) { const gf64x2 v = load_global_at<gf64x2>(p, byte_off); double2 r; r.x = v.x; r.y = v.y; return r; }
 __device__ __forceinline__ double2 load_global(const double2 *p, uint32_t i) { const gf64x2 v = as_global(reinterpret_cast<const gf64x2 *>(p))[i]; double2 r; r.x = v.x; r.y = v.y; return r; }
 
 // ---------------------------------------------------------------------------

@@ -320,10 +320,12 @@ __device__ __forceinline__ void epilogue_word_offsets16(uint32_t (&at)[8], int64
     const int c = tile16_c_of(lane), g = tile16_g_of(lane);
     const int32_t n_qg = (B + 31) >> 5;
     const uint32_t plane_dist = epi.count_planes ? (uint32_t)((int64_t)n_qg * epi.plane_stride) : 0u;
+    // (32-bit arithmetic throughout: the launcher sends shards of 2^28 rows and more elsewhere)
+    const uint32_t col0 = (uint32_t)colbase + (uint32_t)c, last = (uint32_t)(n_rows - 1), half = (uint32_t)(g >> 1) * plane_dist;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int64_t col = colbase + j * 16 + c;
-        at[j] = (uint32_t)(col < n_rows ? col : n_rows - 1) + (uint32_t)(g >> 1) * plane_dist;      // clamped, never branched around
+        const uint32_t col = col0 + 16u * j;
+        at[j] = (col < last ? col : last) + half;                                                    // clamped, never branched around
     }
 }
 
@@ -338,11 +340,11 @@ __device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         // the plane of word 2 t of (query group): a wave-uniform base; the lane's offset picks word 2 t or 2 t + 1
-        const gptr<uint32_t> plane = as_global(has_cp ? epi.count_planes + ((int64_t)(2 * t) * n_qg + qgc) * epi.plane_stride
-                                                      : reinterpret_cast<const uint32_t *>(epi.rowc));
+        const uint32_t *plane = has_cp ? epi.count_planes + ((int64_t)(2 * t) * n_qg + qgc) * epi.plane_stride
+                                       : reinterpret_cast<const uint32_t *>(epi.rowc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t wv = plane[at[j]];
+            const uint32_t wv = load_global_at<uint32_t>(plane, at[j] * 4u);
             w[j][t] = has_cp ? wv : 0u;
         }
     }
@@ -351,13 +353,13 @@ __device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const
 __device__ __forceinline__ void epilogue_issue_loads16(EpiTileLoads16 &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                        const FusedEpilogue &epi, int lane)
 {
-    const int c = tile16_c_of(lane);
+    const uint32_t col0 = (uint32_t)colbase + (uint32_t)tile16_c_of(lane), last = (uint32_t)(n_rows - 1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int64_t col = colbase + j * 16 + c;
-        const uint32_t colc = (uint32_t)(col < n_rows ? col : n_rows - 1);     // clamped, never branched around
-        L.rc[j] = load_global(epi.rowc, colc);
-        L.rf[j] = load_global(epi.i8_rowf, colc);
+        const uint32_t col = col0 + 16u * j;
+        const uint32_t off = (col < last ? col : last) * 16u;                  // clamped, never branched around; rows < 2^28
+        L.rc[j] = load_global_at_d2(epi.rowc, off);
+        L.rf[j] = load_global_at_f4(epi.i8_rowf, off);
     }
     uint32_t at[8];
     epilogue_word_offsets16(at, colbase, B, n_rows, epi, lane);

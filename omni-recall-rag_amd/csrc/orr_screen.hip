@@ -1416,7 +1416,7 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
         // 129+ queries: the tile on 16 x 16 x 64 MFMAs, unless the shard is so large that its epilogue's 32-bit word offsets
         // inside a pair of count planes would not do (then the 32 x 32 x 32 form).  Measured on one box, eight-wave form long
         // gone: 1M x 3072 rows x 256 queries 0.89 -> 0.85 ms, x 1024: 3.23 -> 2.92 ms; C3 (4 launches) 2.23 -> 2.13 ms each.
-        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30) && D / 64 > kS4NB;
+        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30) && n_rows < ((int64_t)1 << 28) && D / 64 > kS4NB;
         if (tile16 && B > 256) ORR_LAUNCH_I8W16(false);
         else if (tile16 && B > 128) ORR_LAUNCH_I8W16(true);
         else if (B > 256) ORR_LAUNCH_I8W4(8, false);
