@@ -8,6 +8,7 @@ offsets beyond 2^31 bytes x 50, 64 sample segments, tens of GB of shadow):
 Size-independent properties (planted row wins, batched = exact kernel, limit prefix = oracle) plus which kernels ran
 and that nothing had to be repeated."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -59,6 +60,17 @@ def test_c3_batch_of_256_planted_rows_win_and_equal_the_exact_kernel(c3):
     assert st["screen_i8_fused"]["launches"] == 4 and st["screen_i8_prefix"]["launches"] == 1, sorted(st)
     assert "dot_exact" not in st and "gemm_dot_bf16x3" not in st, sorted(st)
     assert ss["passes"] == 1 and ss["requeried"] == 0 and ss["overflowed_queries"] == 0 and ss["survivors_max"] < 8192, ss
+    # which workgroup multiplies which output tiles must not show in what survives the screen (a request stream that crossed
+    # to its workgroup's next tile wrongly once did, by 7 pairs in 35,000, behind identical top-10 lists)
+    os.environ["ORR_SCREEN_GRID"] = "64"
+    try:
+        idx.reset_search_stats()
+        rows_g, scores_g, counts_g = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n)
+        ss_g = idx.search_stats()
+    finally:
+        os.environ.pop("ORR_SCREEN_GRID", None)
+    assert ss_g["survivors_total"] == ss["survivors_total"] and ss_g["survivors_max"] == ss["survivors_max"], (ss_g, ss)
+    assert np.array_equal(rows_g, rows) and np.array_equal(scores_g, scores) and np.array_equal(counts_g, counts)
     # 32 of the queries again through the reference-arithmetic kernel over every fp32 row: identical rows, order and fp64 scores
     idx.set_option("two_stage", 0)
     try:
