@@ -98,3 +98,40 @@ def test_c5_shard_shape_through_search_shard_and_merge(c5_shard):
     finally:
         idx.set_option("two_stage", 1)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[0][0, 0] == planted[0]
+
+
+def test_c5_shard_shape_hybrid_batch_of_300_does_not_depend_on_the_workgroup_count(c5_shard):
+    """The C5 form on this shard: 300 hybrid queries (two query tiles per row tile, four row ranges of the 16 x 16 x 64
+    screening GEMM).  What survives the screen, and the results, are the same with 64 persistent workgroups as with one per
+    CU; eight of the queries equal the reference-arithmetic kernel over every row."""
+    import os
+    P, syn, idx, rows, dim, n_total, row_base = c5_shard
+    B = 300
+    q, planted = _queries_planted_in(syn, 1000, B, dim, row_base, row_base + rows, "cuda:0")
+    terms = []
+    for b in range(B):
+        toks = syn.token_ids(planted[b], 1)[0][:2]
+        terms.append(P.text.query_terms(" ".join(syn.vocab_word(int(t)).decode() for t in toks)) if b % 4 else [])
+    idx.set_profiling(True)
+    idx.reset_search_stats()
+    r_a, s_a, c_a = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n_total)
+    st, ss_a = idx.kernel_stats(), idx.search_stats()
+    idx.set_profiling(False)
+    assert st["screen_i8_fused"]["launches"] >= 4, sorted(st)
+    assert list(r_a[:, 0]) == planted
+    os.environ["ORR_SCREEN_GRID"] = "64"
+    try:
+        idx.reset_search_stats()
+        r_g, s_g, c_g = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n_total)
+        ss_g = idx.search_stats()
+    finally:
+        os.environ.pop("ORR_SCREEN_GRID", None)
+    assert ss_g["survivors_total"] == ss_a["survivors_total"] and ss_g["survivors_max"] == ss_a["survivors_max"], (ss_g, ss_a)
+    assert np.array_equal(r_g, r_a) and np.array_equal(s_g, s_a) and np.array_equal(c_g, c_a)
+    idx.set_option("two_stage", 0)
+    try:
+        for b0 in (0, 296):
+            r, s, c = idx.search(q[b0:b0 + 4], terms[b0:b0 + 4], syn.NOW_TICKS, 10, candidate_limit=n_total)
+            assert np.array_equal(r, r_a[b0:b0 + 4]) and np.array_equal(s, s_a[b0:b0 + 4]), b0
+    finally:
+        idx.set_option("two_stage", 1)
