@@ -133,7 +133,7 @@ struct orr_index {
     int64_t row_base = 0;
     hipStream_t stream = nullptr;      // main stream: dots, fused score, selection
     hipStream_t stream_kw = nullptr;   // keyword scan runs beside the HBM-bound dot kernel
-    hipEvent_t ev_inputs = nullptr, ev_kw_done = nullptr, ev_main_ready = nullptr, ev_range[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_inputs = nullptr, ev_kw_done = nullptr, ev_main_ready = nullptr, ev_range[15] = {};     // (one per row range but the first: 16 ranges at most)
     std::mutex mu;
 
     // corpus, in append order until seal, in candidate order afterwards
@@ -495,6 +495,14 @@ int read_device_array_checked(FILE *f, T *dptr, size_t count, std::vector<uint8_
 
 }  // namespace
 
+// the events that release the later row ranges' count words (one per range but the first)
+static bool create_range_events(hipEvent_t (&ev)[15])
+{
+    for (hipEvent_t &e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
+
 extern "C" {
 
 int orr_abi_version(void) { return ORR_ABI_VERSION; }
@@ -537,9 +545,7 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
         hipEventCreateWithFlags(&idx->ev_inputs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&idx->ev_range[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&idx->ev_range[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&idx->ev_range[2], hipEventDisableTiming) != hipSuccess ||
+        !create_range_events(idx->ev_range) ||
         hipEventCreateWithFlags(&idx->ev_q, hipEventDisableTiming) != hipSuccess) {
         orr_index_destroy(idx);
         return fail(ORR_EDEVICE, "cannot create streams on device %d", cfg->device);
@@ -1197,9 +1203,7 @@ int orr_index_view(orr_index *parent, orr_index **out)
         hipEventCreateWithFlags(&v->ev_inputs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_range[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_range[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_range[2], hipEventDisableTiming) != hipSuccess ||
+        !create_range_events(v->ev_range) ||
         hipEventCreateWithFlags(&v->ev_q, hipEventDisableTiming) != hipSuccess) {
         orr_index_destroy(v);
         return fail(ORR_EDEVICE, "cannot create streams on device %d", parent->device);
@@ -1817,16 +1821,20 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             // multiplied (the GEMM leaves half of the HBM bandwidth unused; in front of it the count words were 0.5 of the
             // 1.6 ms a 10M-row, 256-query batch spends before its GEMM starts, 2.7 of 6.9 ms at 12.5M rows x 1024 queries).
             int n_ranges = 1;
-            int64_t range_row[5] = {0, n, n, n, n};
+            int64_t range_row[17];
+            range_row[0] = 0;
+            for (int r = 1; r <= 16; ++r) range_row[r] = n;
             const double plane_bytes_per_row = 4.0 * orr::kCountPlanes * (double)((B + 31) / 32);
             if (kw.bitmaps && !ts_gemv) {
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
                 if (prefix_i8 && two_stage && n >= (int64_t)2000000) {
-                    n_ranges = 4;
+                    // four ranges, eight for more than 256 queries (the first range's count words sit in front of the GEMM: 4 planes
+                    // x 4 B per row and 32 queries)
+                    n_ranges = B > 256 ? 8 : 4;                     // (12.5M rows x 1024 queries: 43.0 / 41.1 / 41.0 ms per batch with 4 / 8 / 16)
                     // (boundaries on whole rounds of the persistent GEMM -- 256 workgroups x 256-row tiles: every workgroup of a
                     // launch then multiplies the same number of tiles; only the last range ends on a partial round)
                     constexpr int64_t kRound = 256 * 256;
-                    for (int r = 1; r < 4; ++r) range_row[r] = (n * r / 4 + kRound / 2) / kRound * kRound;
+                    for (int r = 1; r < n_ranges; ++r) range_row[r] = (n * r / n_ranges + kRound / 2) / kRound * kRound;
                 }
                 Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[1] - range_row[0]));
                 HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, 0, range_row[1]));
