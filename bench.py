@@ -95,6 +95,7 @@ def host_probe():
         out["cpus_in_affinity_mask"] = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    out["cpu_quota"] = cgroup_cpu_quota()
     rc, txt = _run_quiet(["dotnet", "--version"])
     out["dotnet"] = txt.strip().splitlines()[0] if rc == 0 and txt.strip() else "unavailable"
     rc, txt = _run_quiet(["/opt/rocm/bin/rocminfo"])
@@ -114,6 +115,25 @@ def host_probe():
         # dense int8 MFMA: 32x32x32 x 2 ops per 32 cycles per SIMD, 4 SIMDs per CU
         gpu["mfma_i8_peak_tops_at_max_clock"] = gpu["compute_units"] * 4 * 2048 * gpu["max_clock_mhz"] * 1e6 / 1e12
     return out
+
+
+def cgroup_cpu_quota():
+    """CPUs the container may actually use (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`); None = no limit
+    set.  Reported beside os_cpu_count: a 256-CPU box hands a one-GPU container about 16 cores."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        return None if quota <= 0 else round(quota / period, 2)
+    except Exception:
+        return None
 
 
 def spawn_ranks(args, argv):
@@ -368,7 +388,7 @@ def oracle_leg(args, env, idx, gen, n_total, B_headline, probe):
     P, torch, dev = env["P"], env["torch"], env["dev"]
     m = min(args.cpu_sample_rows, n_total)
     nq = min(args.cpu_sample_queries, B_headline)
-    threads = max(1, min(probe.get("cpus_in_affinity_mask") or probe["os_cpu_count"] or 1, 64))
+    threads = max(1, min(probe.get("cpus_in_affinity_mask") or probe["os_cpu_count"] or 1, 256))   # every CPU in the affinity mask
     emb = torch.cat([gen.embeddings(r0, min(32768, m - r0), args.dim, dev).cpu() for r0 in range(0, m, 32768)]).numpy()
     created = gen.created_ticks(0, m, n_total, dev).cpu().numpy()
     pool, off = gen.contents(0, m, dev)
@@ -407,10 +427,11 @@ def oracle_leg(args, env, idx, gen, n_total, B_headline, probe):
     del cos, top
     cpu = {
         "value": rows_per_s / n_total, "unit": "queries/s", "cores": threads, "kind": "port",
-        "sample": f"{nq} queries x the newest {m} of {n_total} rows x {args.dim}-d scored by the C oracle (reference arithmetic, "
-                  f"full hybrid, candidate_limit = {m}) on {threads} threads in {dt:.2f}s; value = row-rate / rows per query of the "
-                  f"headline corpus (linear extrapolation in rows)",
-        "os_cpu_count": probe["os_cpu_count"], "cpus_in_affinity_mask": probe.get("cpus_in_affinity_mask"),
+        "sample": f"{nq} queries x newest {m} of {n_total} rows, C oracle, {threads} threads, {dt:.2f}s; value linear in rows",
+        "sample_note": f"{nq} queries x the newest {m} of {n_total} rows x {args.dim}-d scored by the C oracle (reference arithmetic, "
+                       f"full hybrid, candidate_limit = {m}) on {threads} threads in {dt:.2f}s; value = row-rate / rows per query of the "
+                       f"headline corpus (linear extrapolation in rows)",
+        "os_cpu_count": probe["os_cpu_count"], "cpus_in_affinity_mask": probe.get("cpus_in_affinity_mask"), "cpu_quota": probe.get("cpu_quota"),
         "threads_used": threads, "parallel_speedup_over_one_thread": (m * nq / dt) / (m / dt1),
         "single_thread_value": (m / dt1) / n_total,
         "dotnet": probe["dotnet"],
@@ -427,6 +448,101 @@ def oracle_leg(args, env, idx, gen, n_total, B_headline, probe):
                       f"(same kernels as the timed steps) against the oracle's ranked row ids and unrounded fp64 scores for the first {nq}"}
     return cpu, parity
 
+
+
+# ------------------------------------------------------------------------------------------------
+# the driver's record: ONE short last line on stdout; the whole document goes to a file
+# ------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 1800       # bytes; the driver keeps ~2,000 characters of stdout (round 2's 21 KB line could not be parsed)
+
+
+def _r(x, digits=4):
+    """Numbers to `digits` significant digits: a 17-digit double is 20 bytes of a 1.8 KB line."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _pick(d, keys, digits=4):
+    return {k: _r(d[k], digits) for k in keys if d is not None and k in d}
+
+
+def compact_line(out, full_path=None):
+    """The contract's JSON line (task statement + tier section (4)), from the full document: every key the driver and
+    the judge read, numbers rounded, no prose beyond `config.workload` and `cpu_baseline.sample`.  Anything that would
+    push it past COMPACT_LIMIT is dropped in a fixed order (legs first), never the contract keys."""
+    c = {k: _r(out.get(k), 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    c["config"] = _pick(cfg, ("workload", "name", "corpus_rows", "queries_per_step") + (("rows_per_gpu", "parallelism") if (out.get("n_gpus") or 1) > 1 else ()))
+    rf = out.get("roofline")
+    if rf:
+        c["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step",
+                                   "algo_bytes_per_launch", "frac_survey_8d"), 5)
+        if "mfma" in rf:
+            c["roofline"]["mfma_frac"] = _r(rf["mfma"].get("frac"))
+        if "step_hbm_frac" in rf:
+            c["roofline"]["step_hbm_frac"] = _r(rf["step_hbm_frac"])
+    else:
+        c["roofline"] = None
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        c["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "sample", "threads_used", "os_cpu_count", "cpu_quota", "dotnet"))
+    elif "cpu_baseline" in out:
+        c["cpu_baseline"] = None
+    if out.get("parity"):
+        c["parity"] = _pick(out["parity"], ("rank_identical", "max_abs_score_delta", "rows_checked", "queries_checked", "candidate_limit"))
+    for k in ("rank1_is_planted_row", "rccl_ranks_seen", "collectives_per_step", "backend", "error"):
+        if k in out:
+            c[k] = _r(out[k])
+    if isinstance(out.get("two_steps_in_flight"), dict) and "value" in out["two_steps_in_flight"]:
+        c["two_in_flight_qps"] = _r(out["two_steps_in_flight"]["value"])
+    ss = out.get("search_stats") or {}
+    if ss:
+        c["search_stats"] = _pick(ss, ("passes", "requeried", "overflowed_queries", "exact_pass_queries", "survivors_per_query", "pass_mode"))
+    legs = {}
+    for name, leg in (out.get("legs") or {}).items():
+        if not isinstance(leg, dict) or "value" not in leg:
+            continue
+        lr = leg.get("roofline") or {}
+        short = name.replace("_rows", "").replace("_queries", "q").replace("_query", "q").replace("cosine_only", "cos")
+        legs[short] = [_r(leg["value"], 3), _r(leg.get("ms_per_step"), 3), _r(lr.get("avg_launch_ms"), 3), _r(lr.get("frac"), 3)]
+    if legs:
+        c["legs_qps_ms_kernelms_frac"] = legs
+    c["total_s"] = out.get("total_s")
+    if full_path:
+        c["full"] = full_path
+    # shrink in a fixed order if needed; the contract keys stay
+    for drop in ("legs_qps_ms_kernelms_frac", "search_stats", "two_in_flight_qps", "full"):
+        if len(json.dumps(c, separators=(",", ":"))) <= COMPACT_LIMIT:
+            break
+        c.pop(drop, None)
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:                      # a runaway string (an error text, a path): cut the prose, keep the numbers
+        for holder, key in ((c.get("cpu_baseline") or {}, "sample"), (c, "error"), (c.get("config") or {}, "parallelism")):
+            if isinstance(holder.get(key), str):
+                holder[key] = holder[key][:120]
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """Full document -> bench_full.json (and gpurun_out/ when that exists); compact line -> the LAST line of stdout."""
+    full_path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    json.dump(out, f, indent=1)
+                full_path = full_path or os.path.relpath(os.path.join(d, "bench_full.json"), ROOT)
+        except OSError:
+            pass
+    sys.stdout.flush()
+    print(compact_line(out, full_path), flush=True)
 
 # ------------------------------------------------------------------------------------------------
 def main():
@@ -528,10 +644,11 @@ def main():
     if rank == 0:
         cfg_name = config_name(rows, dim, B, world, not args.no_terms)
         out = {
-            "metric": "queries/sec at top-k=10 over N x 3072-d chunks; score delta vs C# reference (oracle) in `parity`",
+            "metric": "queries/sec at top-k=10 over N x 3072-d chunks; score delta vs C# reference in `parity`",
             "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 screen (bounded, all rows) + f32 x f32 -> f64 exact re-score of the survivors (reference arithmetic)",
+            "dtype": "i8 screen + f32*f32->f64 exact re-score",
+            "dtype_note": "int8 screen with a rigorous per-pair bound over all rows, then f32 x f32 -> f64 re-score of the survivors in the reference's arithmetic",
             "data": "synthetic",
             "config": {"workload": head["workload"], "name": cfg_name, "corpus_rows": n_total, "rows_per_gpu": rows,
                        "queries_per_step": B, "options": args.set_option, "steps_in_flight": 1,
@@ -559,7 +676,7 @@ def main():
             out["cpu_baseline"] = cpu
         elif world == 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
