@@ -112,7 +112,11 @@ typedef struct orr_search_stats {
     int64_t vocab_tokens;        /* distinct whitespace-free tokens of the shard's contents (the keyword index)  */
     int64_t kw_hits_total;       /* (distinct query term, vocabulary token containing it) pairs, summed over passes */
     int64_t kw_passes;           /* passes that had query terms                                                */
-    int64_t reserved[2];
+    int64_t pass_mode;           /* what the LAST device pass ran: 0 no two-stage pass (exact kernel, unfused batched pass,
+                                    large-k sort); 1 two-stage on the int8 shadow; 2 two-stage on the bf16 shadow; 3 two-stage
+                                    WITHOUT a shadow (fp32 rows converted inside the kernel: "two_stage" = 2, or the shadow
+                                    did not fit in device memory and "two_stage" = 1 fell back)                          */
+    int64_t reserved[1];
 } orr_search_stats;
 
 int         orr_abi_version(void);
@@ -188,6 +192,17 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q,
                      const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
                      int64_t candidate_limit, orr_candidate *out);
 
+/* The same with the two per-call choices as ARGUMENTS instead of sticky index options ("shard_topk", "shard_pass", which
+ * orr_search_shard reads): topk = the caller's k when > 0 (the two-stage floor then comes from the k-th best score of the
+ * sampled prefix, not the k'-th: fewer survivors; valid across shards, the global k-th best is at least every shard's);
+ * pass = 0 the library's choice, 1 the unfused batched pass, 2 the reference-arithmetic pass over every row (the repeat of
+ * queries orr_merge_candidates could not certify).  Passes 1 and 2 keep one number per (query,row): they run over slices
+ * of the batch so that their workspace stays below 4 GiB whatever B. */
+int orr_search_shard_ex(orr_index *idx, int32_t B, int32_t dim, const float *q,
+                        const uint8_t *terms_utf8, const uint32_t *term_off,
+                        const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
+                        int64_t candidate_limit, int32_t topk, int32_t pass, orr_candidate *out);
+
 /* Row-sharded corpus, step 2 (host only, no GPU needed): merges the gathered
  * records of n_shards shards ([n_shards][B][kprime+1], host memory), rescoring
  * every candidate in the reference's exact arithmetic and ranking with the exact
@@ -200,6 +215,15 @@ int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_
                          const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
                          int64_t *out_rows, double *out_scores, int32_t *out_counts,
                          int32_t *out_uncertified);
+
+/* The same, also telling WHICH queries were certified: out_certified[B] (may be NULL), 1 = the query's top-k is final.  The
+ * caller repeats only the others (as a compacted sub-batch, through orr_search_shard_ex with pass = 2, then a larger kprime):
+ * every rank of a multi-process job holds identical gathered bytes, so all ranks pick the same sub-batch without a collective. */
+int orr_merge_candidates_ex(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all,
+                            int32_t index_dim, int32_t dim, const float *q_host,
+                            const uint32_t *query_term_off, int64_t now_ticks, int32_t topk,
+                            int64_t *out_rows, double *out_scores, int32_t *out_counts,
+                            int32_t *out_uncertified, uint8_t *out_certified);
 
 /* ---- shard file ---------------------------------------------
  * A sealed shard as one binary file (embeddings, exact norms, timestamps, row ids and the
@@ -266,6 +290,19 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value);
  * memory), i.e. sum_k bf16(q_k) bf16(e_k) accumulated in fp32 on the matrix cores.  Lets a test check the
  * bound the pass relies on.  Needs the bf16 shadow (ORR_ENOMEM when it does not fit); dim % 64 == 0. */
 int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, float *out);
+
+/* Diagnostic: the RAW int32 accumulators of the int8 screening GEMM (K2j), out_dots[B][orr_index_rows] (host or device), as
+ * one FORM of the kernel computes them -- 0: eight-wave 32x32x32 tile (what batches of up to 64 queries, the sampled prefix
+ * and the bf16 shadow run), 1: four-wave 32x32x32 tile (65..128 queries, very large shards), 2: four-wave 16x16x64 tile
+ * (129+ queries: the dominant kernel of config C3/C5) -- with the same K loop, operand rings, request streams and persistent
+ * walk of the output tiles as the fused launches of a search; only the scoring epilogue is replaced by a store.  nt_rows:
+ * rows requested non-temporal (what a search does for batches of one query tile).  The integer work the screen does in
+ * place of RecallSearchService.cs:77-82 is checkable bit for bit this way: out_iq[B][dim] / out_ie[rows][dim] (either may be
+ * NULL) receive the quantised int8 images the product multiplies (queries: one level; rows: the shard's int8 shadow, untiled),
+ * and out_dots must equal out_iq x out_ie^T exactly.  dim % 128 == 0; forms 1 and 2 need dim >= 448.  ORR_ENOMEM without room
+ * for the shadow. */
+int orr_index_screen_i8_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, int32_t form, int32_t nt_rows,
+                             int32_t *out_dots, int8_t *out_iq, int8_t *out_ie);
 
 /* ---- measurement ---------------------------------------------------------*/
 /* enabled: 0 off; 1 an event pair around every kernel; 2 only around the one launch per search that streams every row

@@ -44,7 +44,7 @@ class OrrKernelStat(C.Structure):
 class OrrSearchStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("searches", "queries", "passes", "requeried", "overflowed_queries", "buffer_growths",
                                          "exact_pass_queries", "survivors_total", "survivor_samples", "survivors_max",
-                                         "survivor_capacity", "vocab_tokens", "kw_hits_total", "kw_passes")] + [("reserved", C.c_int64 * 2)]
+                                         "survivor_capacity", "vocab_tokens", "kw_hits_total", "kw_passes", "pass_mode")] + [("reserved", C.c_int64 * 1)]
 
 
 def _load(path: str) -> C.CDLL:
@@ -80,6 +80,10 @@ hip.orr_search_batch.restype = C.c_int
 hip.orr_search_batch.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]
 hip.orr_search_shard.restype = C.c_int
 hip.orr_search_shard.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp]
+hip.orr_search_shard_ex.restype = C.c_int
+hip.orr_search_shard_ex.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp]
+hip.orr_merge_candidates_ex.restype = C.c_int
+hip.orr_merge_candidates_ex.argtypes = [_i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]
 hip.orr_merge_candidates.restype = C.c_int
 hip.orr_merge_candidates.argtypes = [_i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]
 hip.orr_index_save.restype = C.c_int
@@ -96,6 +100,8 @@ hip.orr_index_view.restype = C.c_int
 hip.orr_index_view.argtypes = [_vp, C.POINTER(_vp)]
 hip.orr_index_screen_dots.restype = C.c_int
 hip.orr_index_screen_dots.argtypes = [_vp, _i32, _i32, _vp, _vp]
+hip.orr_index_screen_i8_dots.restype = C.c_int
+hip.orr_index_screen_i8_dots.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]
 hip.orr_index_set_profiling.restype = C.c_int
 hip.orr_index_set_profiling.argtypes = [_vp, _i32]
 hip.orr_index_kernel_stats.restype = C.c_int
@@ -184,8 +190,8 @@ host.orrh_batcher_stats.argtypes = [_vp, _vp, _vp, _vp]
 EXPORTED_HIP_SYMBOLS = [
     "orr_abi_version", "orr_device_count", "orr_last_error", "orr_index_create", "orr_index_destroy",
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
-    "orr_search_shard", "orr_merge_candidates", "orr_index_set_profiling", "orr_index_kernel_stats",
-    "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_view",
+    "orr_search_shard", "orr_search_shard_ex", "orr_merge_candidates", "orr_merge_candidates_ex", "orr_index_set_profiling", "orr_index_kernel_stats",
+    "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_screen_i8_dots", "orr_index_view",
     "orr_index_delete_rows", "orr_index_live_rows", "orr_index_search_stats",
     "orr_cluster_create", "orr_cluster_destroy", "orr_cluster_shards", "orr_cluster_shard", "orr_cluster_seal", "orr_cluster_rows",
     "orr_cluster_search_batch", "orr_cluster_search_stats",

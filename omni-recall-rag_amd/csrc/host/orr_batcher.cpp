@@ -60,9 +60,14 @@ namespace {
 // resolution), so no two production requests ever carry the same now_ticks; the batch is answered at ONE clock, the
 // latest of its requests' (the reference reads the clock per chunk, RecallSearchService.cs:117; one frozen clock per
 // search is this build's documented rule F3, and requests of one batch are at most max_wait_us apart).
-bool compatible(const Request *a, const Request *b)
+// ... but only clocks that can belong to one batch: requests that really arrive together are at most the collection window
+// plus the time they queued behind a running batch apart (one second of slack covers that); a caller that passes explicit or
+// replayed clocks (tests, deterministic re-ranking, backfills) hours apart gets its own batch per clock instead of scores
+// computed at somebody else's now_ticks.
+bool compatible(const Request *a, const Request *b, int64_t clock_slack_ticks)
 {
-    return a->dim == b->dim && a->candidate_limit == b->candidate_limit;
+    const int64_t d = a->now_ticks > b->now_ticks ? a->now_ticks - b->now_ticks : b->now_ticks - a->now_ticks;
+    return a->dim == b->dim && a->candidate_limit == b->candidate_limit && d <= clock_slack_ticks;
 }
 
 void run_batch(orr_index *index, std::vector<Request *> &batch)
@@ -121,7 +126,7 @@ void worker_loop(orrh_batcher *b, orr_index *index)
         std::vector<Request *> batch;
         for (;;) {
             for (auto it = b->queue.begin(); it != b->queue.end() && (int32_t)batch.size() < b->max_batch;) {
-                if (batch.empty() || compatible(batch[0], *it)) {
+                if (batch.empty() || compatible(batch[0], *it, (int64_t)b->max_wait_us * 10 + 10000000)) {     // (10 ticks per microsecond)
                     batch.push_back(*it);
                     it = b->queue.erase(it);
                 } else {

@@ -190,7 +190,7 @@ struct orr_index {
     // search workspace
     DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero, ws_norm_a;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start, ws_qsub;
-    DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta;
+    DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta, ws_tickets;
     size_t bitmaps_clean = 0;          // leading bytes of ws_bitmaps known to be zero (cleared again behind every search)
     const void *bitmaps_clean_of = nullptr;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm, pin_cnt, pin_kwcnt;
@@ -594,7 +594,7 @@ void orr_index_destroy(orr_index *idx)
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start, &idx->ws_qsub,
-                      &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta};
+                      &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta, &idx->ws_tickets};
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
     idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
@@ -1239,6 +1239,54 @@ int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q
     return ORR_OK;
 }
 
+int orr_index_screen_i8_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, int32_t form, int32_t nt_rows, int32_t *out_dots,
+                             int8_t *out_iq, int8_t *out_ie)
+{
+    if (!idx || !q || B <= 0 || form < 0 || form > 2) return fail(ORR_EINVAL, "orr_index_screen_i8_dots: bad argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_screen_i8_dots: the index is not sealed");
+    if (dim != idx->dim || dim <= 0 || dim % 128 != 0) return fail(ORR_EINVAL, "orr_index_screen_i8_dots: dim must equal the index dimension and be a multiple of 128");
+    if (form > 0 && dim / 64 <= 6) return fail(ORR_EINVAL, "orr_index_screen_i8_dots: the four-wave forms need dim >= 448");
+    if (idx->n_rows <= 0) return ORR_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    ORR_TRY(ensure_i8_shadow(idx));
+    if (!idx->i8_ready) return fail(ORR_ENOMEM, "orr_index_screen_i8_dots: the int8 shadow does not fit in device memory");
+    hipStream_t s = idx->stream;
+    const size_t n = (size_t)idx->n_rows;
+    ORR_TRY(idx->ws_q.reserve(sizeof(float) * (size_t)B * dim));
+    ORR_TRY(idx->ws_q8.reserve(2 * (size_t)B * dim));
+    ORR_TRY(idx->ws_q8s1.reserve(sizeof(float) * (size_t)B));
+    ORR_TRY(idx->ws_q8err.reserve(2 * sizeof(double) * (size_t)B));
+    ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, dim)));
+    HIP_TRY(hipMemcpyAsync(idx->ws_q.p, q, sizeof(float) * (size_t)B * dim, hipMemcpyDefault, s));
+    // the same quantisation and tiling the searches use (one int8 level per query)
+    HIP_TRY(orr::launch_i8_queries(idx->ws_q.as<float>(), B, dim, idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), s,
+                                   idx->ws_q8err.as<double>() + B));
+    HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, dim, idx->ws_qtiled.p, s));
+    if (out_dots) {
+        ORR_TRY(idx->ws_dotf.reserve(sizeof(int32_t) * (size_t)B * n));
+        HIP_TRY(hipMemsetAsync(idx->ws_dotf.p, 0xAB, sizeof(int32_t) * (size_t)B * n, s));     // (an element the kernel never writes shows up as 0xABABABAB)
+        ORR_TRY(idx->ws_tickets.reserve(sizeof(uint32_t) * 8 * 16));
+        HIP_TRY(hipMemsetAsync(idx->ws_tickets.p, 0, sizeof(uint32_t) * 8 * 16, s));
+        {
+            Timed t(idx, form == 0 ? "screen_i8_dots_w8" : form == 1 ? "screen_i8_dots_w4" : "screen_i8_dots_w16",
+                    1.0 * (double)n * dim + 1.0 * (double)B * dim + 4.0 * (double)B * (double)n);
+            HIP_TRY(orr::launch_screen_i8_dots_raw(idx->ws_qtiled.p, B, idx->emb_i8.p, idx->n_rows, dim, idx->ws_dotf.as<int32_t>(),
+                                                   idx->n_rows, form, nt_rows != 0, s, idx->ws_tickets.as<uint32_t>()));
+        }
+        HIP_TRY(hipMemcpyAsync(out_dots, idx->ws_dotf.p, sizeof(int32_t) * (size_t)B * n, hipMemcpyDefault, s));
+    }
+    if (out_iq) HIP_TRY(hipMemcpyAsync(out_iq, idx->ws_q8.p, (size_t)B * dim, hipMemcpyDefault, s));
+    if (out_ie) {
+        ORR_TRY(idx->ws_raw.reserve(n * (size_t)dim));
+        HIP_TRY(orr::launch_i8_untile(idx->emb_i8.p, idx->n_rows, dim, idx->ws_raw.p, s));
+        HIP_TRY(hipMemcpyAsync(out_ie, idx->ws_raw.p, n * (size_t)dim, hipMemcpyDefault, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    collect_events(idx);
+    return ORR_OK;
+}
+
 int orr_index_set_profiling(orr_index *idx, int32_t enabled)
 {
     if (!idx) return fail(ORR_EINVAL, "null index");
@@ -1647,6 +1695,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     bool records_have_dots = false;    // two-stage: exact dots copied from the survivors' buffer
     bool ts_gemv = false;              // two-stage with the streaming screen (1..8 queries)
     bool prefix_i8 = false;            // the sampled prefix went through the int8 screening GEMM: its keys are lower bounds
+    int pass_mode = 0;                 // orr_search_stats.pass_mode of this pass
     int64_t dotf_rows = n;             // columns of d_dotf
     if (use_cos && use_mfma) {
         if (!ts_stream && B <= 64) {
@@ -1951,8 +2000,12 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                             HIP_TRY(hipEventRecord(idx->ev_range[r - 1], k));
                         }
                     }
+                    // output-tile tickets of the 16 x 16 x 64 form: eight counters per launch, cleared once per pass
+                    ORR_TRY(idx->ws_tickets.reserve(sizeof(uint32_t) * 8 * 16));
+                    HIP_TRY(hipMemsetAsync(idx->ws_tickets.p, 0, sizeof(uint32_t) * 8 * 16, s));
                     for (int r = 0; r < n_ranges; ++r) {
                         if (r > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_range[r - 1], 0));
+                        epi.tickets = idx->ws_tickets.as<uint32_t>() + 8 * r;
                         const double rows_r = (double)(range_row[r + 1] - range_row[r]);
                         Timed t(idx, "screen_i8_fused", rows_r * ((double)idx->dim + 32.0 + (epi.count_planes ? 16.0 * (double)((B + 31) / 32) : 0.0)) +
                                                         1.0 * (double)B * idx->dim);
@@ -2016,6 +2069,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 }
                 records_have_dots = true;
                 a.used_two_stage = true;
+                pass_mode = (gemm_i8 || ts_i8) ? 1 : (((ts_gemv && !ts_i8) || (idx->opt_two_stage == 1 && idx->shadow_ready)) ? 2 : 3);
             } else {
             {
                 Timed t(idx, "select_floor", 0.0);
@@ -2112,6 +2166,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         HIP_TRY(hipMemcpyAsync(idx->pin_cand.p, d_cand, rec_bytes, hipMemcpyDeviceToHost, s));
     }
     g_ht.mark(3);
+    idx->sstats.pass_mode = pass_mode;
     HIP_TRY(hipStreamSynchronize(s));
     if (bm_bytes) {            // every kernel that read the bitmaps is done: clear them for the next search
         HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, bm_bytes, idx->stream_kw));
@@ -2451,39 +2506,32 @@ int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset)
     return ORR_OK;
 }
 
-int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
-                     const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
-                     int64_t candidate_limit, orr_candidate *out)
+// One shard pass of `a` (all of its queries) with the records written to out[first .. first + a.B) (host or device memory), then --
+// inside the call -- the queries whose survivors' buffers overflowed again with buffers sized from the measured counts
+// (clustered rows, cosine-only scores): a caller that only saw ORR_CAND_OVERFLOW could but repeat the whole batch through
+// the exact pass on every shard.  Caller holds idx->mu.
+static int shard_pass_into(orr_index *idx, BatchArgs a, int32_t kprime, int64_t candidate_limit, orr_candidate *out, size_t first,
+                           bool dev_out)
 {
-    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, kprime};
-    ORR_TRY(check_batch(idx, a, "orr_search_shard"));
-    if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
-    if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
-    std::lock_guard<std::mutex> lock(idx->mu);
-    // the caller's escalation after a merge that could not certify every query (orr_merge_candidates)
-    a.no_fuse = idx->opt_shard_pass >= 1;
-    a.force_exact = idx->opt_shard_pass >= 2;
-    // the floor of the two-stage pass: from the k-th best of the sample when the caller told its topK (valid across shards:
-    // the global k-th best is at least every shard's), else from the k'-th
-    if (idx->opt_shard_topk > 0) a.topk = std::min<int32_t>(kprime, idx->opt_shard_topk);
-    const bool dev_out = is_device_pointer(out);
+    const int32_t B = a.B;
     const size_t rec_q = sizeof(orr_candidate) * ((size_t)kprime + 1);
-    if (dev_out) a.out_dev = out;               // records written where the caller wants them (the all-gather's send buffer)
+    unsigned char *dst = reinterpret_cast<unsigned char *>(out) + rec_q * first;
+    a.out_dev = dev_out ? reinterpret_cast<orr_candidate *>(dst) : nullptr;   // records written where the caller wants them (the all-gather's send buffer)
     ORR_TRY(run_shard(idx, a, kprime, false, nullptr, nullptr));
-    if (!dev_out) HIP_TRY(hipMemcpy(out, idx->ws_cand.p, rec_q * (size_t)B, hipMemcpyDefault));
-    idx->sstats.searches += 1; idx->sstats.queries += B; idx->sstats.passes += 1;
-    // Survivors' buffers that overflowed (clustered rows, cosine-only scores): THOSE queries again, here, with buffers sized
-    // from the measured counts -- a caller that only sees ORR_CAND_OVERFLOW could but repeat the whole batch through the
-    // exact pass on every shard.
+    if (!dev_out) HIP_TRY(hipMemcpy(dst, idx->ws_cand.p, rec_q * (size_t)B, hipMemcpyDefault));
+    idx->sstats.passes += 1;
     const int64_t n = participating_rows(idx, candidate_limit);
-    for (int round = 0; round < 4 && a.used_two_stage && (int32_t)idx->h_survivors.size() == B; ++round) {
+    std::vector<int32_t> active((size_t)B);             // the queries the last pass answered, in the batch's numbering
+    std::iota(active.begin(), active.end(), 0);
+    bool two_stage = a.used_two_stage;
+    for (int round = 0; round < 4 && two_stage && idx->h_survivors.size() == active.size(); ++round) {
         std::vector<int32_t> over;
         uint32_t worst = 0;
-        for (int32_t b = 0; b < B; ++b) {
-            const uint32_t cnt = idx->h_survivors[(size_t)b];
+        for (size_t i = 0; i < active.size(); ++i) {       // (statistics: only the queries this pass ran)
+            const uint32_t cnt = idx->h_survivors[i];
             idx->sstats.survivors_total += cnt; idx->sstats.survivor_samples += 1;
             if ((int64_t)cnt > idx->sstats.survivors_max) idx->sstats.survivors_max = cnt;
-            if (cnt > idx->pass_cap) { over.push_back(b); worst = std::max(worst, cnt); }
+            if (cnt > idx->pass_cap) { over.push_back(active[i]); worst = std::max(worst, cnt); }
         }
         if (over.empty()) break;
         idx->sstats.overflowed_queries += (int64_t)over.size();
@@ -2500,17 +2548,62 @@ int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, con
         ORR_TRY(run_shard(idx, sub, kprime, false, nullptr, nullptr));          // records in idx->ws_cand
         idx->sstats.passes += 1; idx->sstats.requeried += (int64_t)over.size();
         for (size_t i = 0; i < over.size(); ++i)
-            HIP_TRY(hipMemcpy(reinterpret_cast<unsigned char *>(out) + rec_q * (size_t)over[i],
-                              static_cast<const unsigned char *>(idx->ws_cand.p) + rec_q * i, rec_q, hipMemcpyDefault));
-        if (!sub.used_two_stage || idx->h_survivors.size() != over.size()) break;
-        // the counts of the repeated queries, back in the batch's numbering, for the next round's check
-        std::vector<uint32_t> merged((size_t)B, 0u);
-        for (size_t i = 0; i < over.size(); ++i) merged[(size_t)over[i]] = idx->h_survivors[i];
-        idx->h_survivors.swap(merged);
-        a.used_two_stage = true;
+            HIP_TRY(hipMemcpy(dst + rec_q * (size_t)over[i], static_cast<const unsigned char *>(idx->ws_cand.p) + rec_q * i, rec_q, hipMemcpyDefault));
+        two_stage = sub.used_two_stage;
+        active.swap(over);
     }
     idx->sstats.survivor_capacity = idx->survivor_cap;
     return ORR_OK;
+}
+
+int orr_search_shard_ex(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
+                        const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
+                        int64_t candidate_limit, int32_t topk, int32_t pass, orr_candidate *out)
+{
+    BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, kprime};
+    ORR_TRY(check_batch(idx, a, "orr_search_shard"));
+    if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
+    if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
+    if (pass < 0 || pass > 2 || topk < 0) return fail(ORR_EINVAL, "orr_search_shard_ex: pass takes 0, 1 or 2 and topk must be >= 0");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    // the caller's escalation after a merge that could not certify every query (orr_merge_candidates)
+    a.no_fuse = pass >= 1;
+    a.force_exact = pass >= 2;
+    // the floor of the two-stage pass: from the k-th best of the sample when the caller told its topK (valid across shards:
+    // the global k-th best is at least every shard's), else from the k'-th
+    if (topk > 0) a.topk = std::min<int32_t>(kprime, topk);
+    const bool dev_out = is_device_pointer(out);
+    idx->sstats.searches += 1; idx->sstats.queries += B;
+    // passes that keep one number per (query,row) -- the unfused and the exact one -- run over slices of the batch, so that
+    // their workspace stays bounded whatever the batch (1024 queries x 12.5M rows x 8 B = 102 GB in one piece)
+    const int64_t n = std::max<int64_t>(1, participating_rows(idx, candidate_limit));
+    if (pass >= 1 && B > 1 && (size_t)B * (size_t)n * 8 > kPassWorkspaceBytes) {
+        const int32_t per = (int32_t)std::max<size_t>(1, kPassWorkspaceBytes / ((size_t)n * 8));
+        for (int32_t b0 = 0; b0 < B; b0 += per) {
+            std::vector<int32_t> part((size_t)std::min<int32_t>(per, B - b0));
+            std::iota(part.begin(), part.end(), b0);
+            SubBatch sb;
+            BatchArgs sub;
+            ORR_TRY(build_subset(idx, a, part, sb, sub));
+            sub.no_fuse = a.no_fuse; sub.force_exact = a.force_exact;
+            ORR_TRY(shard_pass_into(idx, sub, kprime, candidate_limit, out, (size_t)b0, dev_out));
+        }
+        return ORR_OK;
+    }
+    return shard_pass_into(idx, a, kprime, candidate_limit, out, 0, dev_out);
+}
+
+int orr_search_shard(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
+                     const uint32_t *term_off, const uint32_t *query_term_off, int64_t now_ticks, int32_t kprime,
+                     int64_t candidate_limit, orr_candidate *out)
+{
+    if (!idx) return fail(ORR_EINVAL, "orr_search_shard: null index");
+    int32_t topk = 0, pass = 0;
+    {   // the sticky per-index forms of the two arguments ("shard_topk", "shard_pass"); orr_search_shard_ex takes them per call
+        std::lock_guard<std::mutex> lock(idx->mu);
+        topk = idx->opt_shard_topk; pass = idx->opt_shard_pass;
+    }
+    return orr_search_shard_ex(idx, B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, kprime, candidate_limit, topk, pass, out);
 }
 
 int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all, int32_t index_dim,
@@ -2525,6 +2618,20 @@ int orr_merge_candidates(int32_t n_shards, int32_t B, int32_t kprime, const orr_
     if (use_cos && !q_host) return fail(ORR_EINVAL, "orr_merge_candidates: q_host is required with dim %d", dim);
     return merge_impl(n_shards, B, kprime, all, dim, use_cos, q_host, nullptr, query_term_off, now_ticks, topk, out_rows,
                       out_scores, out_counts, out_uncertified);
+}
+
+int orr_merge_candidates_ex(int32_t n_shards, int32_t B, int32_t kprime, const orr_candidate *all, int32_t index_dim,
+                            int32_t dim, const float *q_host, const uint32_t *query_term_off, int64_t now_ticks,
+                            int32_t topk, int64_t *out_rows, double *out_scores, int32_t *out_counts,
+                            int32_t *out_uncertified, uint8_t *out_certified)
+{
+    if (n_shards < 1 || B < 1 || kprime < 1) return fail(ORR_EINVAL, "orr_merge_candidates: sizes must be positive");
+    if (!all || !query_term_off || !out_rows || !out_scores) return fail(ORR_EINVAL, "orr_merge_candidates: null argument");
+    if (dim < 0 || index_dim < 0) return fail(ORR_EINVAL, "orr_merge_candidates: negative dimension");
+    const bool use_cos = dim > 0 && dim == index_dim;
+    if (use_cos && !q_host) return fail(ORR_EINVAL, "orr_merge_candidates: q_host is required with dim %d", dim);
+    return merge_impl(n_shards, B, kprime, all, dim, use_cos, q_host, nullptr, query_term_off, now_ticks, topk, out_rows,
+                      out_scores, out_counts, out_uncertified, out_certified);
 }
 
 int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, const uint8_t *terms_utf8,
@@ -2629,6 +2736,7 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
         return ORR_OK;
     }));
     c->sstats.passes += 1;
+    c->sstats.pass_mode = c->shards[0]->sstats.pass_mode;
     if (depth > 0) c->sstats.requeried += nb;
     std::vector<uint8_t> cert((size_t)nb, 1);
     int32_t unc = 0;
@@ -2780,6 +2888,15 @@ int orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, const float
     if (dim > 0 && is_device_pointer(q_host)) return fail(ORR_EINVAL, "orr_cluster_search_batch: the query vectors must be in host memory (every shard's device reads them)");
     std::lock_guard<std::mutex> lock(c->mu);
     if (!c->sealed) return fail(ORR_ESTATE, "orr_cluster_search_batch: the cluster is not sealed");
+    {   // rows deleted from a shard since the seal (orr_index_delete_rows on orr_cluster_shard(i)) shift the candidate_limit prefix
+        // of every shard behind it: the dead-row prefix sums are taken afresh for every search
+        int64_t dead = 0;
+        for (orr_index *sh : c->shards) {
+            std::lock_guard<std::mutex> sl(sh->mu);
+            sh->dead_before = dead;
+            dead += (int64_t)sh->dead.size();
+        }
+    }
     const int32_t take = std::max<int32_t>(1, topk);
     int64_t n_total = 0;
     for (orr_index *sh : c->shards) n_total += participating_rows(sh, candidate_limit);

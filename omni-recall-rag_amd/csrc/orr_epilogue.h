@@ -417,6 +417,15 @@ __device__ __forceinline__ float acc16_as_float_here(int token)
     return (float)r;
 }
 
+// the raw accumulator (diagnostic dots form of the kernel)
+template <int IDX>
+__device__ __forceinline__ int acc16_as_int_here(int token)
+{
+    int r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(IDX), "v"(token) : ORR_T16_ACC_CLOBBERS);
+    return r;
+}
+
 template <int QDEPTH, typename HOOK = EpiNoHook>
 __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                  const FusedEpilogue &epi, int lane, EpiParked *queue, int queue_stride, uint32_t idx_salt,

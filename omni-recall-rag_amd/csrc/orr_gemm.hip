@@ -398,8 +398,7 @@ static hipError_t launch_bf16x3_variant(const __bf16 *q_hi, const __bf16 *q_lo, 
     const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     constexpr size_t lds_bytes = sizeof(__bf16) * (PROD == 3 ? 2 : 1) * (kBfBM + BN) * kBfLd;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED, PROD>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const hipError_t attr = ensure_max_dynamic_lds<gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED, PROD>>((int)lds_bytes);     // per device
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((gemm_dot_bf16x3_kernel<NT, TWO_STAGE, FUSED, PROD>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, q_hi, q_lo, B,
                        E, row_first, n_rows, D, S, s_stride, (int32_t)n_ntiles, n_mtiles, epi);

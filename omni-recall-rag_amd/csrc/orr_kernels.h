@@ -7,7 +7,40 @@
 
 #include "../../include/omnirecall_hip.h"
 
+#include <atomic>
+
 namespace orr {
+
+// Per-DEVICE launch state (orr_cluster drives several devices from one process, one host thread per shard): the
+// max-dynamic-LDS attribute of a kernel and a device's CU count are established on every device they are used on, not on
+// whichever device happened to be current at the first call of the process.
+inline int current_device_ordinal()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d;
+}
+template <auto KERNEL>
+hipError_t ensure_max_dynamic_lds(int bytes)
+{
+    static std::atomic<uint64_t> done[4] = {};            // one bit per device ordinal (256 devices)
+    const int dev = current_device_ordinal() & 255;
+    if ((done[dev >> 6].load(std::memory_order_acquire) >> (dev & 63)) & 1ull) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[dev >> 6].fetch_or(1ull << (dev & 63), std::memory_order_release);
+    return e;
+}
+inline int device_cu_count()
+{
+    static std::atomic<int> cus[256] = {};
+    const int dev = current_device_ordinal() & 255;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n > 0 ? n : 0;
+}
 
 constexpr int kSelWidth = 64;        // entries a wave keeps while selecting (one per lane)
 constexpr int kSelSegRows = 4096;    // rows one workgroup of fuse_select scans
@@ -164,6 +197,7 @@ struct FusedEpilogue {
     SelEntry *buf;                     // [B][cap]
     uint32_t cap;
     unsigned long long *stamps;        // diagnostic (ORR_SCREEN_STAMPS=file): s_memtime at the phases of every output tile, else null
+    uint32_t *tickets;                 // [8] zeroed counters of ONE launch of the 16 x 16 x 64 screening GEMM (output tiles beyond a workgroup's first two are drawn from them), or null: static assignment
 };
 // K2b: S (or the fused epilogue) from three bf16 MFMA products of hi/lo splits (see orr_gemm.hip
 // for the error bound); D % 64 == 0.  q_split_ws: 4*B*D bytes filled by launch_split_queries.
@@ -211,6 +245,11 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
 // The same product over rows [0, n_rows) with the integer dots written out: S[b][r] = (float)I (the sampled prefix).
 hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, float *S,
                                  int64_t s_stride, hipStream_t s);
+// Diagnostic: the raw int32 accumulators of one FORM of the kernel (0 eight-wave, 1 four-wave 32 x 32 x 32, 2 four-wave
+// 16 x 16 x 64; forms 1 and 2 need D / 64 > 6), rows requested non-temporal or not; and the shadow untiled again.
+hipError_t launch_screen_i8_dots_raw(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, int32_t *S,
+                                     int64_t s_stride, int32_t form, bool nt_rows, hipStream_t s, uint32_t *tickets = nullptr);
+hipError_t launch_i8_untile(const void *tiled, int64_t n_rows, int32_t D, void *out_linear, hipStream_t s);
 // Two-stage pass helpers (orr_gemm.hip).
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,
                                        const int64_t *created, KwView kw, const QueryConst *qc, int64_t now_ticks,

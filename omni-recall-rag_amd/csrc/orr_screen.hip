@@ -284,7 +284,10 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = b0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
+                    if (row < B && col < n_rows) {
+                        if (I8 && (flags & 2)) reinterpret_cast<int *>(S)[(int64_t)row * s_stride + col] = (int)acc[i][j][e];   // raw accumulator (diagnostic)
+                        else S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
+                    }
                 }
             }
     } else {
@@ -344,6 +347,7 @@ __global__ __launch_bounds__(512, 1) void screen_bf16_kernel(const __bf16 *__res
 // ---------------------------------------------------------------------------
 constexpr int kS4NA = 3, kS4NB = 6;
 constexpr int kS4Queue = 6;
+constexpr int kS16Queue = 5;                            // the 16 x 16 x 64 form parks five: the sixth plane's first word is its ticket mailbox
 constexpr int kS4EpiBytes = kS4Queue * 8 * 256 + 4096;
 constexpr int kS4Lds = (kS4NA + kS4NB) * kScImage + kS4EpiBytes;
 static_assert(kS4Lds <= 160 * 1024, "the rings and the epilogue's region must fit a CU's LDS");
@@ -561,9 +565,13 @@ __global__ __launch_bounds__(256, 1) void screen_tile4_kernel(const __bf16 *__re
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = b0 + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    if (row < B && col < n_rows) S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
+                    if (row < B && col < n_rows) {
+                        if (I8 && (flags & 2)) reinterpret_cast<int *>(S)[(int64_t)row * s_stride + col] = (int)acc[i][j][e];   // raw accumulator (diagnostic)
+                        else S[(int64_t)row * s_stride + col] = (float)acc[i][j][e];
+                    }
                 }
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the stores: the counted waits of the next tile's K loop count requests only)
         if (has_next) { if (row_loader) refill(std::true_type{}); else refill(std::false_type{}); }
     } else {
         uint32_t salt = 0;
@@ -625,7 +633,8 @@ __global__ __launch_bounds__(256, 1) void screen_tile4_kernel(const __bf16 *__re
 // The stored swizzle was made for 32-row fragments; a fragment here takes its 16 rows in the order tile16_row, which makes
 // the 16-row x 4-chunk reads conflict-free on it.  The epilogue for this accumulator layout: fused_epilogue16 (orr_epilogue.h).
 // ---------------------------------------------------------------------------
-template <bool NT>
+// DOTS (diagnostic, orr_index_screen_i8_dots): no scoring epilogue -- the raw int32 accumulators go to S[query][row].
+template <bool NT, bool DOTS = false>
 __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
                                                               const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
                                                               int32_t D, float *__restrict__ S, int64_t s_stride,
@@ -685,14 +694,38 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     int ring_a = 0, ring_b = 0;
     bool first = true;
     int tile_seq = 0;
+    // ---- TICKETS (epi.tickets != nullptr): a workgroup's first two output tiles are assigned statically (ids blockIdx.x and
+    // blockIdx.x + gridDim.x), every later one is drawn from a counter when the workgroup gets there -- workgroups that run
+    // ahead (a CU whose tiles had nothing to park, an XCD with the shorter way to the rows) take more tiles instead of idling
+    // at the end of the launch (static assignment: workgroups ended 5-12 % apart by the stamps).  One counter for the launch
+    // when the batch is one query tile (every row tile is read once, by whoever); one per XCD otherwise (the query tiles of a
+    // row tile stay on the XCD whose L2 holds the rows).  The valid ids are a dense prefix in both forms -- id < n_ntiles, or
+    // slot id >> 3 < the XCD's slot count -- so "none left" is final.  The ticket for the tile AFTER NEXT is drawn where the
+    // epilogue's loads go out (in the tail of the K loop, where this wave has nothing in flight: its value comes back with
+    // them) and handed to the other waves through LDS behind the barrier in front of the epilogue: the request stream needs
+    // the next tile's id long before the multiplication gets there.
+    const bool dyn = epi.tickets != nullptr;
+    const int xcd = blockIdx.x & 7;
+    const int lim_slots = n_mtiles * ((n_ntiles - xcd + 7) >> 3);
+    auto dyn_checked = [&](int id) { return (n_mtiles == 1 ? id < n_ntiles : (id >> 3) < lim_slots) ? id : total_ids; };
+    auto ticket_id = [&](uint32_t t) {
+        return n_mtiles == 1 ? (int)t + 2 * (int)gridDim.x : ((((int)t + 2 * (int)(gridDim.x >> 3)) << 3) | xcd);
+    };
+    volatile int *const mailbox = reinterpret_cast<volatile int *>(lds_epi + kS16Queue * 8 * 256);     // (the LDS of the parking queue's sixth plane)
+    int id_after = dyn ? dyn_checked((int)blockIdx.x + (int)gridDim.x) : 0;    // ticket mode: the id after the current one
+    if (dyn) {                                                                  // (the request stream of the first tile: as assigned here)
+        s_id = dyn_checked(blockIdx.x);
+        s_src = s_id < total_ids ? stream_src(s_id) : nullptr;
+    }
+    uint32_t ticket = 0u;
 #define ORR_STAMP(k) if (FUSED && epi.stamps && tid == 0 && tile_seq < 64) epi.stamps[((int64_t)blockIdx.x * 64 + tile_seq) * 8 + (k)] = __builtin_amdgcn_s_memtime()
-    for (int id = valid_from(blockIdx.x); id < total_ids;) {
+    for (int id = dyn ? dyn_checked(blockIdx.x) : valid_from(blockIdx.x); id < total_ids;) {
     ORR_STAMP(0);
     // (laundered per output tile: what hangs on the lane number -- fragment offsets, the epilogue's row and query numbers --
     // is made again for every tile instead of living, spilled, across the epilogue)
     int lane_t = lane;
     asm volatile("" : "+v"(lane_t));
-    const int next_id = valid_from(id + gridDim.x);
+    const int next_id = dyn ? id_after : valid_from(id + gridDim.x);
     const bool has_next = next_id < total_ids;
     const int mt = (id >> 3) % n_mtiles, nt = ((id >> 3) / n_mtiles) * 8 + (id & 7);
     const int64_t n0 = row_first + (int64_t)nt * kScBN;
@@ -735,7 +768,8 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     EpiTileLoads16 pre;
     float4 qf_mine = make_float4(0.f, 0.f, 0.f, 0.f);
     auto epilogue_requests = [&]() __attribute__((always_inline)) {
-        if constexpr (FUSED) {
+        if (dyn && tid == 0) ticket = atomicAdd(&epi.tickets[n_mtiles == 1 ? 0 : xcd], 1u);      // (the oldest of what goes out here)
+        if constexpr (FUSED && !DOTS) {
             // laundered once per output tile: otherwise everything derived from these is hoisted out of the persistent loop
             asm volatile("" : "+s"(ep.rowc), "+s"(ep.qc), "+s"(ep.tau), "+s"(ep.qf), "+s"(ep.count_planes), "+s"(ep.plane_stride),
                               "+s"(ep.i8_rowf), "+s"(ep.i8_qs1), "+s"(ep.cnt), "+s"(ep.buf));
@@ -827,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
         s_stage = (s_stage + n_main) % RING;
         // every K-tile of this output tile is requested now: the stream moves on to the workgroup's next one (the refill
         // behind the epilogue starts there)
-        const int nid = valid_from(s_id + gridDim.x);
+        const int nid = next_id;                                           // (= valid_from(s_id + gridDim.x) without tickets: s_id == id here)
         if (nid < total_ids) { s_id = nid; s_k = 0; s_src = stream_src(nid); }
         else { s_k = T; s_src += (int64_t)n_main * kScImage; }
     }
@@ -850,7 +884,29 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     if (row_loader) k_loop(std::true_type{}); else k_loop(std::false_type{});
     ORR_STAMP(1);
 
-    {
+    if constexpr (DOTS) {
+        // element e of lane (c, g) of accumulator tile (i, j) = a[4 (8 i + j) + e] belongs to query 16 i + 4 g + e and row 16 j + c
+        // of the wave's 128 x 128 tile (fused_epilogue16)
+        const int c = tile16_c_of(lane_t), g = tile16_g_of(lane_t);
+        int *Si = reinterpret_cast<int *>(S);
+        static_for<8>([&](auto i_c) {
+            static_for<8>([&](auto j_c) {
+                static_for<4>([&](auto e_c) {
+                    constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, e = decltype(e_c)::value;
+                    const int qi = b0 + wr * 128 + 16 * i + 4 * g + e;
+                    const int64_t col = n0 + wc * 128 + 16 * j + c;
+                    const int v = acc16_as_int_here<4 * (8 * i + j) + e>(acc_token);
+                    if (qi < B && col < n_rows) Si[(int64_t)qi * s_stride + col] = v;
+                });
+            });
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the stores: the counted waits of the next tile's K loop count requests only)
+        if (dyn) {
+            if (tid == 0) *mailbox = dyn_checked(ticket_id(ticket));
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (has_next) { if (row_loader) refill(std::true_type{}); else refill(std::false_type{}); }
+    } else {
         uint32_t salt = 0;
         asm volatile("" : "+s"(salt));
         if (b0 + tid >= B) qf_mine = make_float4(0.f, __builtin_huge_valf(), 0.f, 0.f);    // no query: floor +inf
@@ -864,6 +920,10 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             asm volatile("" : "+v"(pre.rc[j].x), "+v"(pre.rc[j].y));
             asm volatile("" : "+v"(pre.rf[j].x), "+v"(pre.rf[j].y), "+v"(pre.rf[j].z), "+v"(pre.rf[j].w));
             asm volatile("" : "+v"(pre.w[0][j][0]), "+v"(pre.w[0][j][1]));
+        }
+        if (dyn) {                                                         // the ticket came back with the loads above: the id after next, for every wave
+            asm volatile("" : "+v"(ticket));
+            if (tid == 0) *mailbox = dyn_checked(ticket_id(ticket));
         }
         epilogue_issue_later_words16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);    // (they land under the first block's tests)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (bare: __syncthreads() would also wait for outstanding requests)
@@ -883,7 +943,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             };
             if (row_loader) part(std::true_type{}); else part(std::false_type{});
         };
-        fused_epilogue16<kS4Queue>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
+        fused_epilogue16<kS16Queue>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
     }
 #undef ORR_RD
 #undef ORR_SB
@@ -893,6 +953,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     ring_a = (ring_a + T) % kS4NA;
     ring_b = (ring_b + T) % kS4NB;
     id = next_id;
+    if (dyn) id_after = __builtin_amdgcn_readfirstlane(*mailbox);          // (written in front of this tile's epilogue barrier; rewritten behind the next tile's K loop)
     }
 #undef ORR_STAMP
 }
@@ -1343,11 +1404,8 @@ __global__ __launch_bounds__(256) void i8_tile_queries_kernel(const int8_t *__re
 static int64_t screen_grid(int64_t tiles, int32_t k_tiles)
 {
     if (k_tiles < kScNB) return tiles;        // the requests of a tile reach kScNB K-tiles ahead: never past the next output tile
-    static const int64_t cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return (int64_t)0;
-        return (int64_t)(n / 8 * 8);
-    }();
+    const int n_cu = device_cu_count();                                     // (of the CURRENT device: clusters launch on several)
+    const int64_t cus = n_cu >= 8 ? (int64_t)(n_cu / 8 * 8) : 0;
     int64_t per_launch = cus;
     // ORR_SCREEN_GRID=n (diagnostic, read at every launch): n persistent workgroups instead of one per CU -- how the K loop's
     // cycles depend on how many CUs multiply at once, and the test that results do not depend on which
@@ -1379,25 +1437,32 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     constexpr int flags = 1;                                               // rows of single-query-tile launches are requested non-temporal
     // ORR_SCREEN_STAMPS=file (diagnostic): every launch appends its workgroups' per-tile phase stamps to the file
     static const char *stamp_path = getenv("ORR_SCREEN_STAMPS");
-    static unsigned long long *d_stamps = nullptr;
+    static std::atomic<unsigned long long *> d_stamps_of[256] = {};         // (one buffer per device: kernels write it where they run)
     constexpr size_t kStampWords = 256 * 64 * 8;
     FusedEpilogue epi_st = epi;
+    unsigned long long *d_stamps = nullptr;
     if (stamp_path) {
-        if (!d_stamps && hipMalloc(reinterpret_cast<void **>(&d_stamps), kStampWords * 8) != hipSuccess) return hipErrorOutOfMemory;
+        std::atomic<unsigned long long *> &slot = d_stamps_of[current_device_ordinal() & 255];
+        d_stamps = slot.load();
+        if (!d_stamps) {
+            if (hipMalloc(reinterpret_cast<void **>(&d_stamps), kStampWords * 8) != hipSuccess) return hipErrorOutOfMemory;
+            unsigned long long *expected = nullptr;
+            if (!slot.compare_exchange_strong(expected, d_stamps)) { (void)hipFree(d_stamps); d_stamps = expected; }
+        }
         (void)hipMemsetAsync(d_stamps, 0, kStampWords * 8, s);
         epi_st.stamps = d_stamps;
     }
+    // ORR_SCREEN_TICKETS=0 (diagnostic, read at every launch): static assignment of the output tiles, for A/B runs
+    if (const char *t = getenv("ORR_SCREEN_TICKETS")) { if (atoi(t) == 0) epi_st.tickets = nullptr; }
     const FusedEpilogue &epi_use = epi_st;
 #define ORR_LAUNCH_I8(L) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<true, true, L>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_bf16_kernel<true, true, L>>(kScLds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<true, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
 #define ORR_LAUNCH_I8W4(L, NT) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_tile4_kernel<true, true, L, NT>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kS4Lds); \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_tile4_kernel<true, true, L, NT>>(kS4Lds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_tile4_kernel<true, true, L, NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
@@ -1407,8 +1472,7 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     // Measured, 1M x 3072 rows: 128 queries 0.756 -> 0.619 ms, 256: 0.862 -> 0.842, 1024: 3.42 -> 3.30; 64: 0.485 vs 0.506.
     if (B > 64 && D / 64 >= kS4NB) {
 #define ORR_LAUNCH_I8W16(NT) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_tile16_kernel<NT>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kS4Lds); \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_tile16_kernel<NT>>(kS4Lds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_tile16_kernel<NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
@@ -1450,8 +1514,7 @@ hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_t
     if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const FusedEpilogue none{};
 #define ORR_LAUNCH_I8D(L) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<false, true, L>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_bf16_kernel<false, true, L>>(kScLds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<false, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
@@ -1461,6 +1524,90 @@ hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_t
     else if (B > 32) ORR_LAUNCH_I8D(2);
     else ORR_LAUNCH_I8D(1);
 #undef ORR_LAUNCH_I8D
+    return hipGetLastError();
+}
+
+// Diagnostic (orr_index_screen_i8_dots): S[b][r] = the RAW int32 accumulator of the int8 screening GEMM over rows [0, n_rows),
+// computed by the given form of the kernel -- 0: eight-wave 32 x 32 x 32 (LIVE query tiles from B, as launch_screen_i8 picks
+// them), 1: four-wave 32 x 32 x 32, 2: four-wave 16 x 16 x 64 -- with the SAME K loop, rings, requests and persistent walk of the
+// output tiles as the fused launches (only the epilogue differs), so that the integer work is checkable bit for bit.
+hipError_t launch_screen_i8_dots_raw(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, int32_t *S,
+                                     int64_t s_stride, int32_t form, bool nt_rows, hipStream_t s, uint32_t *tickets)
+{
+    if (B <= 0 || n_rows <= 0) return hipSuccess;
+    if (D <= 0 || D % 128 != 0 || !S || form < 0 || form > 2) return hipErrorInvalidValue;
+    const int64_t n_ntiles = (n_rows + kScBN - 1) / kScBN;
+    const int32_t n_mtiles = (B + kScBM - 1) / kScBM;
+    const int64_t blocks = ((n_ntiles + 7) / 8) * 8 * n_mtiles;
+    if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    FusedEpilogue none{};
+    none.tickets = tickets;                                                // (form 2 draws its output tiles from them, as the fused launches do)
+    if (const char *t = getenv("ORR_SCREEN_TICKETS")) { if (atoi(t) == 0) none.tickets = nullptr; }
+    float *Sf = reinterpret_cast<float *>(S);
+    constexpr int flags = 2;                                               // raw accumulators
+    if (form == 0) {
+#define ORR_LAUNCH_I8R(L) do { \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_bf16_kernel<false, true, L>>(kScLds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_bf16_kernel<false, true, L>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(512), kScLds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           Sf, s_stride, (int32_t)n_ntiles, n_mtiles, flags | (nt_rows ? 1 : 0), none); } while (0)
+        if (B > 128) ORR_LAUNCH_I8R(8);
+        else if (B > 64) ORR_LAUNCH_I8R(4);
+        else if (B > 32) ORR_LAUNCH_I8R(2);
+        else ORR_LAUNCH_I8R(1);
+#undef ORR_LAUNCH_I8R
+        return hipGetLastError();
+    }
+    if (D / 64 <= kS4NB) return hipErrorInvalidValue;                      // (the four-wave forms need more K-tiles than their row ring holds)
+#define ORR_LAUNCH_I8R4(L, NT) do { \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_tile4_kernel<false, true, L, NT>>(kS4Lds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_tile4_kernel<false, true, L, NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           Sf, s_stride, (int32_t)n_ntiles, n_mtiles, flags, none); } while (0)
+#define ORR_LAUNCH_I8R16(NT) do { \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_tile16_kernel<NT, true>>(kS4Lds); \
+        if (attr != hipSuccess) return attr; \
+        hipLaunchKernelGGL((screen_tile16_kernel<NT, true>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
+                           static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), (int64_t)0, n_rows, D, \
+                           Sf, s_stride, (int32_t)n_ntiles, n_mtiles, flags, none); } while (0)
+    if (form == 1) {
+        if (B <= 128) ORR_LAUNCH_I8R4(4, true);                            // (65..128 queries in the product; any B <= 128 here)
+        else if (nt_rows) ORR_LAUNCH_I8R4(8, true);
+        else ORR_LAUNCH_I8R4(8, false);
+    } else {
+        if (nt_rows) ORR_LAUNCH_I8R16(true);
+        else ORR_LAUNCH_I8R16(false);
+    }
+#undef ORR_LAUNCH_I8R16
+#undef ORR_LAUNCH_I8R4
+    return hipGetLastError();
+}
+
+// linear [n_rows][D] int8 from the tiled, swizzled image (diagnostic)
+__global__ __launch_bounds__(256) void i8_untile_kernel(const int8_t *__restrict__ tiled, int64_t n_rows, int32_t D, int64_t n_chunks,
+                                                        int8_t *__restrict__ out)
+{
+    const int KT = D / 64;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_chunks; o += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(o & 3);
+        const int rr = (int)((o >> 2) & 255);
+        const int64_t tk = o >> 10;
+        const int kt = (int)(tk % KT);
+        const int64_t row = (tk / KT) * kScBN + rr;
+        const int c = slot ^ ((rr >> 2) & 3);
+        if (row < n_rows) *reinterpret_cast<uint4 *>(out + row * (int64_t)D + kt * 64 + c * 16) = *reinterpret_cast<const uint4 *>(tiled + o * 16);
+    }
+}
+
+hipError_t launch_i8_untile(const void *tiled, int64_t n_rows, int32_t D, void *out_linear, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    if (D <= 0 || D % 128 != 0) return hipErrorInvalidValue;
+    const int64_t n_chunks = (int64_t)(i8_tiled_bytes(n_rows, D) / 16);
+    hipLaunchKernelGGL(i8_untile_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + 255) / 256, 65536)), dim3(256), 0, s,
+                       static_cast<const int8_t *>(tiled), n_rows, D, n_chunks, static_cast<int8_t *>(out_linear));
     return hipGetLastError();
 }
 
@@ -1578,8 +1725,7 @@ hipError_t launch_screen_bf16(const void *q_tiled, int32_t B, const void *e_shad
     const FusedEpilogue none{};
     constexpr int flags = 1;                                               // rows of single-query-tile launches are requested non-temporal
 #define ORR_LAUNCH_LIVE(F, L, E) do { \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(screen_bf16_kernel<F, false, L>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScLds); \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_bf16_kernel<F, false, L>>(kScLds); \
         if (attr != hipSuccess) return attr; \
         hipLaunchKernelGGL((screen_bf16_kernel<F, false, L>), dim3((unsigned)screen_grid(blocks, D / kScBK)), dim3(512), kScLds, s, q_hi, B, eh, row_first, n_rows, D, \
                            S, s_stride, (int32_t)n_ntiles, n_mtiles, flags, E); } while (0)

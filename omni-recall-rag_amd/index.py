@@ -173,16 +173,22 @@ class RecallIndex:
                                        int(topk), int(candidate_limit), _ptr(rows), _ptr(scores), _ptr(counts)))
         return rows, scores, counts
 
-    def search_shard(self, qvecs, queries_terms, now_ticks: int, kprime: int, candidate_limit: int, out=None):
-        """orr_search_shard.  Returns a [B, kprime+1] structured array (or fills `out`, which may be a
-        torch uint8 tensor on the device with B*(kprime+1)*56 bytes)."""
+    def search_shard(self, qvecs, queries_terms, now_ticks: int, kprime: int, candidate_limit: int, out=None,
+                     topk: Optional[int] = None, shard_pass: Optional[int] = None):
+        """orr_search_shard (or, with topk / shard_pass given, orr_search_shard_ex: the caller's k and the pass as call
+        arguments instead of sticky index options).  Returns a [B, kprime+1] structured array (or fills `out`, which may be
+        a torch uint8 tensor on the device with B*(kprime+1)*56 bytes)."""
         B = len(queries_terms)
         dim, q, _keep = self._query_args(qvecs, B)
         pool, toff, qoff = pack_terms(queries_terms)
         if out is None:
             out = np.zeros((B, kprime + 1), dtype=CAND_DTYPE)
-        N.check(N.hip.orr_search_shard(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks,
-                                       int(kprime), int(candidate_limit), _ptr(out)))
+        if topk is None and shard_pass is None:
+            N.check(N.hip.orr_search_shard(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks,
+                                           int(kprime), int(candidate_limit), _ptr(out)))
+        else:
+            N.check(N.hip.orr_search_shard_ex(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks,
+                                              int(kprime), int(candidate_limit), max(0, int(topk or 0)), int(shard_pass or 0), _ptr(out)))
         return out
 
     def view(self) -> "RecallIndex":
@@ -206,6 +212,18 @@ class RecallIndex:
         out = np.empty((q.shape[0], self.rows), dtype=np.float32)
         N.check(N.hip.orr_index_screen_dots(self._h, int(q.shape[0]), int(q.shape[1]), _ptr(q), _ptr(out)))
         return out
+
+    def screen_i8_dots(self, qvecs, form: int, nt_rows: bool = False, images: bool = True):
+        """orr_index_screen_i8_dots: raw int32 accumulators [B, rows] of one form of the int8 screening GEMM (0 eight-wave,
+        1 four-wave 32x32x32, 2 four-wave 16x16x64) and, with images, the int8 images it multiplied ([B, dim], [rows, dim])."""
+        q = np.ascontiguousarray(qvecs, dtype=np.float32)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        B, dim, n = int(q.shape[0]), int(q.shape[1]), self.rows
+        dots = np.empty((B, n), dtype=np.int32)
+        iq = np.empty((B, dim), dtype=np.int8) if images else None
+        ie = np.empty((n, dim), dtype=np.int8) if images else None
+        N.check(N.hip.orr_index_screen_i8_dots(self._h, B, dim, _ptr(q), int(form), 1 if nt_rows else 0, _ptr(dots), _ptr(iq), _ptr(ie)))
+        return dots, iq, ie
 
     def set_profiling(self, on) -> None:
         """False/0 off, True/1 every kernel, 2 only the launch that streams every row (orr_index_set_profiling)."""
@@ -308,9 +326,10 @@ class RecallCluster:
         return d
 
 
-def merge_candidates(all_records: np.ndarray, index_dim: int, qvecs, queries_terms, now_ticks: int, topk: int):
+def merge_candidates(all_records: np.ndarray, index_dim: int, qvecs, queries_terms, now_ticks: int, topk: int, with_certificates: bool = False):
     """orr_merge_candidates over [n_shards, B, kprime+1] records (host).  Returns
-    (rows, scores, counts, uncertified)."""
+    (rows, scores, counts, uncertified) -- with_certificates: (..., uncertified, certified [B] bool) through
+    orr_merge_candidates_ex."""
     assert all_records.dtype == CAND_DTYPE and all_records.ndim == 3
     n_shards, B, kp1 = all_records.shape
     all_records = np.ascontiguousarray(all_records)
@@ -326,6 +345,12 @@ def merge_candidates(all_records: np.ndarray, index_dim: int, qvecs, queries_ter
     scores = np.zeros((B, k), dtype=np.float64)
     counts = np.zeros(B, dtype=np.int32)
     unc = C.c_int32(0)
+    if with_certificates:
+        cert = np.zeros(B, dtype=np.uint8)
+        N.check(N.hip.orr_merge_candidates_ex(n_shards, B, kp1 - 1, _ptr(all_records), index_dim, dim, _ptr(q), _ptr(qoff),
+                                              now_ticks, int(topk), _ptr(rows), _ptr(scores), _ptr(counts),
+                                              C.cast(C.byref(unc), C.c_void_p), _ptr(cert)))
+        return rows, scores, counts, int(unc.value), cert.astype(bool)
     N.check(N.hip.orr_merge_candidates(n_shards, B, kp1 - 1, _ptr(all_records), index_dim, dim, _ptr(q), _ptr(qoff),
                                        now_ticks, int(topk), _ptr(rows), _ptr(scores), _ptr(counts),
                                        C.cast(C.byref(unc), C.c_void_p)))

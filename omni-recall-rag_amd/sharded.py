@@ -82,23 +82,16 @@ class ShardedRecallSearch:
         # shard_search(qvecs [B,dim] np/torch, terms, now, kprime, limit, out=, mode=, topk=) -> records [B,kprime+1]
         self._shard_search = shard_search or self._index_shard_search
         self._pinned = {}                      # name -> pinned host staging tensor (device runs only)
-        self._told_topk = 0
         self.collectives = 0                   # data-path collectives issued so far (diagnostic)
-        self.escalations = 0                   # batches repeated with the exact pass or a larger k'
+        self.escalations = 0                   # passes repeated with the exact pass or a larger k' (for the uncertified queries only)
+        self.escalated_queries = 0             # queries that went through such a repeat (summed over repeats)
+        self._shard_search_done = None         # test hook: called with (records tensor, queries, k') between the shard search and the all-gather
 
     def _index_shard_search(self, q, terms, now, kprime, limit, out=None, mode=0, topk=0):
         # mode 0: the library picks the pass; 2: the exact pass (escalation after a failed certificate).
-        # topk: the caller's k, so that the two-stage floor comes from the k-th best of the sample, not the k'-th
-        if topk != self._told_topk:
-            self.index.set_option("shard_topk", max(0, int(topk)))
-            self._told_topk = topk
-        if mode:
-            self.index.set_option("shard_pass", mode)
-        try:
-            return self.index.search_shard(q, terms, now, kprime, limit, out=out)
-        finally:
-            if mode:
-                self.index.set_option("shard_pass", 0)
+        # topk: the caller's k, so that the two-stage floor comes from the k-th best of the sample, not the k'-th.
+        # Both travel as CALL ARGUMENTS (orr_search_shard_ex): nothing sticky is left on the index for another caller.
+        return self.index.search_shard(q, terms, now, kprime, limit, out=out, topk=max(0, int(topk)), shard_pass=int(mode))
 
     def _to_host(self, name: str, t: torch.Tensor) -> np.ndarray:
         """Device tensor -> numpy through a reused pinned buffer (one asynchronous copy + one stream sync instead of
@@ -218,26 +211,58 @@ class ShardedRecallSearch:
 
     # ---- local scoring, exchange 2, host finish
     def _score_and_merge(self, q_all, q_host, terms_all, B: int, now_ticks: int, topk: int, candidate_limit: int, kprime: int):
+        """Stream contract of the record exchange: orr_search_shard_ex writes this rank's records into `mine` on the library's
+        OWN stream and returns only when they are complete (include/omnirecall_hip.h, conventions: device-resident outputs
+        are complete when the call returns); the collective then reads `mine` on the process group's stream, which was idle
+        or behind work issued before the call.  Nothing of torch's is pending on `mine` either: it is allocated here and
+        never written by torch.  `_shard_search_done` (test hook) sees the buffer between the two."""
         W = self.world
+        k = max(1, int(topk))
+        rows = np.full((B, k), -1, dtype=np.int64)
+        scores = np.zeros((B, k), dtype=np.float64)
+        counts = np.zeros(B, dtype=np.int32)
+        ids = np.arange(B)                                   # queries still to be answered, in the batch's numbering
+        whole = True
         mode = 0
         while True:
-            rec_bytes = B * (kprime + 1) * CAND_DTYPE.itemsize
+            nb = int(ids.shape[0])
+            if whole:
+                q_sub, qh_sub, t_sub = q_all, q_host, terms_all
+            else:
+                # ONLY the queries that could not be certified go through the next, more exact pass, as a compacted sub-batch
+                # (the exact pass keeps 8 bytes per (query,row): 1024 queries x 12.5M rows would be 102 GB).  Every rank holds
+                # the same gathered bytes, hence the same `ids`: no collective is needed to agree on the sub-batch.
+                qh_sub = None if q_host is None else np.ascontiguousarray(q_host[ids])
+                if q_all is None:
+                    q_sub = None
+                elif q_all.device.type == "cuda":
+                    q_sub = q_all.index_select(0, torch.as_tensor(ids, dtype=torch.int64, device=q_all.device)).contiguous()
+                else:
+                    q_sub = torch.from_numpy(qh_sub)
+                t_sub = PackedTerms(pack_terms([terms_all[int(b)] for b in ids]))
+            rec_bytes = nb * (kprime + 1) * CAND_DTYPE.itemsize
             mine = torch.empty(rec_bytes, dtype=torch.uint8, device=self.device)
-            self._shard_search(q_all, terms_all, now_ticks, kprime, candidate_limit, out=mine, mode=mode, topk=max(1, int(topk)))
+            self._shard_search(q_sub, t_sub, now_ticks, kprime, candidate_limit, out=mine, mode=mode, topk=k)
+            if self._shard_search_done is not None:
+                self._shard_search_done(mine, nb, kprime)
             if W > 1:
                 allrec = torch.empty(W * rec_bytes, dtype=torch.uint8, device=self.device)
                 dist.all_gather_into_tensor(allrec, mine, group=self.group)
                 self.collectives += 1
             else:
                 allrec = mine
-            recs = self._to_host("records", allrec).view(CAND_DTYPE).reshape(W, B, kprime + 1)
+            recs = self._to_host("records", allrec).view(CAND_DTYPE).reshape(W, nb, kprime + 1)
             # Every rank finishes EVERY query from the same gathered bytes, so all ranks reach the
             # same "escalate or not" decision without another collective.
-            rows, scores, counts, unc = merge_candidates(recs, self.index_dim, q_host, terms_all, now_ticks, topk)
+            r, s, c, unc, cert = merge_candidates(recs, self.index_dim, qh_sub, t_sub, now_ticks, topk, with_certificates=True)
             total = int(recs[:, 0, kprime]["order_key"].sum())
-            if unc == 0 or kprime >= total:
+            done = cert if (unc > 0 and kprime < total) else np.ones(nb, dtype=bool)
+            rows[ids[done]], scores[ids[done]], counts[ids[done]] = r[done], s[done], c[done]
+            if done.all():
                 return rows, scores, counts
             self.escalations += 1
+            self.escalated_queries += int((~done).sum())
+            ids, whole = ids[~done], False
             if mode == 0:
                 mode = 2                                     # first the exact pass at the same k' (ties at the cut, overflowing survivor buffers)
             else:

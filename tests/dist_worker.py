@@ -100,6 +100,25 @@ def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_querie
             ok = list(rows[i, :counts[i]]) == list(orow) and np.array_equal(scores[i, :counts[i]], osc)
             results.append(bool(ok))
     expected = 8
+    # ---- queries that cannot be certified in a larger batch: a zero vector without terms scores 0.1 * recency only, so its whole
+    # top-3 are the newest rows, all on shard 0, whose k' = 3 cut-off then EQUALS the third best score (and the rows of a
+    # document share their timestamp: exact ties across the cut) -> not certified; queries whose top-3 spread over shards are.
+    # ONLY the tied queries may be repeated (as a compacted sub-batch), not the whole batch.
+    B4 = 4
+    q4 = rng.standard_normal((B4, dim)).astype(np.float32)
+    q4[1] = 0.0
+    texts4 = ["alpha the helm", "", "kubernetes", "GAMMA zzz"]
+    esc0, escq0 = front.escalations, front.escalated_queries
+    rows, scores, counts = front.search(torch.from_numpy(q4), [P.text.query_terms(t) if t else [] for t in texts4],
+                                        639144000000000000, 3, n, kprime=3)
+    corpus4 = orc.OracleCorpus(c["emb"], c["created"], c["contents"])
+    for i in range(B4):
+        orow, osc, _ = corpus4.search(q4[i], texts4[i], 639144000000000000, 3, candidate_limit=n)
+        results.append(bool(list(rows[i, :counts[i]]) == list(orow) and np.array_equal(scores[i, :counts[i]], osc)))
+    esc, escq = front.escalations - esc0, front.escalated_queries - escq0
+    print("tied-query trial: escalations", esc, "escalated queries", escq, flush=True)
+    results.append(bool(esc >= 1 and world <= escq < esc * world * B4))      # repeats happened, and never for the whole batch
+    expected += B4 + 1
     if long_queries:
         # rank 1 originates a query whose terms alone exceed the first collective's budget; rank 0 one with 300 terms
         long_text = " ".join(["kubernetes"] + ["w%04dxyzxyzxyzxyz" % i for i in range(60)]) if rank == 1 else \

@@ -83,6 +83,42 @@ def test_requests_with_their_own_clocks_still_share_batches():
     idx.close()
 
 
+def test_replayed_clocks_hours_apart_do_not_share_a_batch():
+    """Requests with explicit clocks far apart (tests, deterministic re-ranking, backfills) are answered at THEIR OWN clock:
+    only clocks within the collection window (+ 1 s of queueing slack) may share a batch."""
+    P = pkg()
+    rng = np.random.default_rng(23)
+    n, dim = 2000, 64
+    c = random_corpus(rng, n, dim)
+    idx = build_index(c)
+    corpus = oracle_corpus(c)
+    n_req = 12
+    qs = rng.standard_normal((n_req, dim)).astype(np.float32)
+    hour = 36_000_000_000
+    nows = [NOW - (i % 3) * 5 * hour + i for i in range(n_req)]                       # three clock groups, five hours apart
+    batcher = P.MicroBatcher(idx, max_batch=32, max_wait_us=50000)
+    results = [None] * n_req
+    barrier = threading.Barrier(n_req)
+
+    def work(i):
+        barrier.wait()
+        results[i] = batcher.search(qs[i], P.text.query_terms("alpha helm"), nows[i], 5, candidate_limit=n, with_clock=True)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_req)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert batcher.stats()["batches"] >= 3
+    for i in range(n_req):
+        rows, scores, clock = results[i]
+        assert abs(clock - nows[i]) < hour, (i, clock - nows[i])                       # answered within its own group
+        orow, osc, _ = corpus.search(qs[i], "alpha helm", clock, 5, candidate_limit=n)
+        assert list(rows) == list(orow) and np.array_equal(scores, osc), i
+    batcher.close()
+    idx.close()
+
+
 def test_concurrent_unbatched_searches_are_serialised_safely():
     P = pkg()
     rng = np.random.default_rng(18)

@@ -116,3 +116,47 @@ def test_cluster_rejects_shards_out_of_order():
     with pytest.raises(P.OrrError):
         cl.seal()
     cl.close()
+
+
+def test_cluster_deletes_after_the_seal_shift_the_candidate_limit_of_later_shards():
+    """orr_index_delete_rows on shard 0 AFTER orr_cluster_seal: candidate_limit counts live rows only, so a limit that
+    crosses the shard boundary must reach further into shard 1 -- exactly as one index (and the oracle) over the
+    surviving rows does.  (Round 2 fixed each shard's dead-rows-before at seal time.)"""
+    P = pkg()
+    rng = np.random.default_rng(612)
+    n, dim = 1800, 32
+    c = _sorted_corpus(rng, n, dim, p_null=0.0)
+    cl = P.RecallCluster([0, 0, 0], dim)
+    bounds = [0, 600, 1200, n]
+    _fill(P, cl, c, bounds)
+    # deletes in shard 0 (40 rows) and shard 1 (25 rows), after the seal
+    dead0 = sorted(int(x) for x in rng.choice(np.arange(0, 600), 40, replace=False))
+    dead1 = sorted(int(x) for x in rng.choice(np.arange(600, 1200), 25, replace=False))
+    assert cl.shard(0).delete_rows(dead0) == 40
+    assert cl.shard(1).delete_rows(dead1) == 25
+    gone = set(dead0) | set(dead1)
+    keep = [r for r in range(n) if r not in gone]
+    corpus = orc.OracleCorpus([c["emb"][r] for r in keep], c["created"][keep], [c["contents"][r] for r in keep])
+    B = 6
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    # limits (in LIVE rows): inside shard 0, just across the first boundary, across both, everything
+    for topk, limit in ((5, 300), (8, 560 + 15), (8, 600 + 30), (10, 1135 + 20), (10, 1200 + 50), (10, n)):
+        rows, scores, counts = cl.search(qs, terms, NOW, topk, candidate_limit=limit)
+        for b in range(B):
+            orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=limit)
+            want = [keep[int(r)] for r in orow]                      # the oracle numbers the surviving rows 0..; ids are the original positions
+            assert list(rows[b, :counts[b]]) == want, (topk, limit, b)
+            assert np.array_equal(scores[b, :counts[b]], osc), (topk, limit, b)
+    # more deletes between two searches are seen by the next one
+    more = [r for r in range(0, 600) if r not in gone][:10]
+    assert cl.shard(0).delete_rows(more) == 10
+    gone |= set(more)
+    keep = [r for r in range(n) if r not in gone]
+    corpus = orc.OracleCorpus([c["emb"][r] for r in keep], c["created"][keep], [c["contents"][r] for r in keep])
+    rows, scores, counts = cl.search(qs, terms, NOW, 8, candidate_limit=600)
+    for b in range(B):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 8, candidate_limit=600)
+        assert list(rows[b, :counts[b]]) == [keep[int(r)] for r in orow] and np.array_equal(scores[b, :counts[b]], osc), b
+    cl.close()

@@ -135,3 +135,101 @@ def test_c5_shard_shape_hybrid_batch_of_300_does_not_depend_on_the_workgroup_cou
             assert np.array_equal(r, r_a[b0:b0 + 4]) and np.array_equal(s, s_a[b0:b0 + 4]), b0
     finally:
         idx.set_option("two_stage", 1)
+
+
+def _hybrid_terms(P, syn, planted, every=1):
+    terms = []
+    for b, row in enumerate(planted):
+        toks = syn.token_ids(row, 1)[0][[3, 40, 77]]
+        words = " ".join(syn.vocab_word(int(t)).decode() for t in toks)
+        terms.append(P.text.query_terms(f"What is the {words}") if b % every == 0 or every == 1 else [])
+    return terms
+
+
+def test_c5_per_gpu_shape_batch_of_1024_hybrid_queries(c5_shard):
+    """BASELINE.json configs[4] as one of its eight GPUs sees it: 12.5M rows x 3072, ONE batch of 1024 full-hybrid queries
+    (four 256-query tiles per row tile, eight row ranges of the 16 x 16 x 64 screening GEMM).  One pass, nothing overflows,
+    nothing falls back to the exact pass; planted rows win; queries from all four query tiles equal the reference-arithmetic
+    kernel over every row; survivors and results do not depend on the number of persistent workgroups."""
+    import os
+    P, syn, idx, rows, dim, n_total, row_base = c5_shard
+    B = 1024
+    q, planted = _queries_planted_in(syn, 5000, B, dim, row_base, row_base + rows, "cuda:0")
+    terms = _hybrid_terms(P, syn, planted)
+    assert all(len(t) == 3 for t in terms)
+    idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n_total)         # (workspaces and the adapted sample settle)
+    idx.set_profiling(True)
+    idx.reset_search_stats()
+    r_a, s_a, c_a = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n_total)
+    st, ss_a = idx.kernel_stats(), idx.search_stats()
+    idx.set_profiling(False)
+    print("c5 shard, 1024 hybrid queries:", ss_a, {k: round(v["total_ms"], 3) for k, v in st.items()})
+    assert st["screen_i8_fused"]["launches"] == 8, {k: v["launches"] for k, v in st.items()}     # eight row ranges, one launch each
+    assert "dot_exact" not in st and "gemm_dot_bf16x3" not in st, sorted(st)
+    assert ss_a["passes"] == 1 and ss_a["requeried"] == 0 and ss_a["overflowed_queries"] == 0 and ss_a["exact_pass_queries"] == 0, ss_a
+    assert ss_a["pass_mode"] == 1, ss_a                                      # the int8 shadow was there (two_stage = 1 ran as such)
+    assert list(r_a[:, 0]) == planted and (c_a == 10).all()
+    os.environ["ORR_SCREEN_GRID"] = "64"
+    try:
+        idx.reset_search_stats()
+        r_g, s_g, c_g = idx.search(q, terms, syn.NOW_TICKS, 10, candidate_limit=n_total)
+        ss_g = idx.search_stats()
+    finally:
+        os.environ.pop("ORR_SCREEN_GRID", None)
+    assert ss_g["survivors_total"] == ss_a["survivors_total"] and ss_g["survivors_max"] == ss_a["survivors_max"], (ss_g, ss_a)
+    assert np.array_equal(r_g, r_a) and np.array_equal(s_g, s_a) and np.array_equal(c_g, c_a)
+    idx.set_option("two_stage", 0)
+    try:
+        for b0 in (0, 252, 256, 508, 764, 1020):                              # four queries each: every query tile, both ends of two of them
+            r, s, c = idx.search(q[b0:b0 + 4], terms[b0:b0 + 4], syn.NOW_TICKS, 10, candidate_limit=n_total)
+            assert np.array_equal(r, r_a[b0:b0 + 4]) and np.array_equal(s, s_a[b0:b0 + 4]), b0
+    finally:
+        idx.set_option("two_stage", 1)
+
+
+def test_c4_per_gpu_shape_one_query_and_256_cosine_only(c5_shard):
+    """BASELINE.json configs[3] on one of its eight GPUs: cosine (+ recency) only, one query per step (the streaming int8
+    screen over 12.5M rows) and 256 per step, through orr_search_shard + orr_merge_candidates; against orr_search_batch on
+    the shard and, for a few queries, the reference-arithmetic kernel."""
+    P, syn, idx, rows, dim, n_total, row_base = c5_shard
+    kprime = 32
+    q, planted = _queries_planted_in(syn, 9000, 256, dim, row_base, row_base + rows, "cuda:0")
+    qh = q.cpu().numpy()
+    none = [[] for _ in range(256)]
+    # ---- one query per step
+    idx.set_profiling(True)
+    for b in (0, 1, 2):
+        idx.reset_search_stats()
+        recs = idx.search_shard(q[b:b + 1], none[:1], syn.NOW_TICKS, kprime, candidate_limit=n_total)
+        assert not (recs["flags"][:, kprime] & 4).any()
+        mrows, mscores, mcounts, unc = P.merge_candidates(recs[None], dim, qh[b:b + 1], none[:1], syn.NOW_TICKS, 10)
+        assert unc == 0 and int(mrows[0, 0]) == planted[b] and int(mcounts[0]) == 10
+        r1, s1, _ = idx.search(q[b:b + 1], none[:1], syn.NOW_TICKS, 10, candidate_limit=n_total)
+        assert np.array_equal(r1, mrows) and np.array_equal(s1, mscores)
+    st = idx.kernel_stats()
+    idx.set_profiling(False)
+    assert "screen_gemv_i8" in st and "screen_i8_fused" not in st, sorted(st)        # the stream, not the GEMM
+    # ---- 256 per step (the survivors' buffers and the sampled prefix adapt over the first searches: cosine-only scores have
+    # no steps, DESIGN.md 3)
+    for _ in range(3):
+        recs = idx.search_shard(q, none, syn.NOW_TICKS, kprime, candidate_limit=n_total)
+    idx.set_profiling(True)
+    idx.reset_search_stats()
+    recs = idx.search_shard(q, none, syn.NOW_TICKS, kprime, candidate_limit=n_total)
+    st, ss = idx.kernel_stats(), idx.search_stats()
+    idx.set_profiling(False)
+    print("c4 shard, 256 cosine-only queries:", ss)
+    assert st["screen_i8_fused"]["launches"] >= 1 and "dot_exact" not in st, sorted(st)
+    assert not (recs["flags"][:, kprime] & 4).any(), ss
+    assert ss["exact_pass_queries"] == 0, ss
+    mrows, mscores, mcounts, unc = P.merge_candidates(recs[None], dim, qh, none, syn.NOW_TICKS, 10)
+    assert unc == 0 and list(mrows[:, 0]) == planted and (mcounts == 10).all()
+    r2, s2, _ = idx.search(q, none, syn.NOW_TICKS, 10, candidate_limit=n_total)
+    assert np.array_equal(r2, mrows) and np.array_equal(s2, mscores)
+    idx.set_option("two_stage", 0)
+    try:
+        for b0 in (0, 252):
+            r, s, _ = idx.search(q[b0:b0 + 4], none[:4], syn.NOW_TICKS, 10, candidate_limit=n_total)
+            assert np.array_equal(r, mrows[b0:b0 + 4]) and np.array_equal(s, mscores[b0:b0 + 4]), b0
+    finally:
+        idx.set_option("two_stage", 1)
