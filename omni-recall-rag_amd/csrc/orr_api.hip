@@ -1861,7 +1861,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                 std::min<int64_t>(dotf_rows, n), B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
                                                 lists_total, s, i8p));
             }
-            ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * (size_t)B));
+            ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * 2 * (size_t)B));
             orr::FusedEpilogue epi{};
             epi.count_planes = nullptr;
             epi.plane_stride = (n + 63) / 64 * 64;
@@ -1969,10 +1969,14 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     epi.i8_rowf = idx->i8_rowf.as<float4>();
                     epi.i8_qs1 = idx->ws_q8s1.as<float>();
                 }
-                if (!ts_gemv)                    // the streaming kernels score in fp64 directly, no fp32 pre-filter constants
+                if (!ts_gemv) {                  // the streaming kernels score in fp64 directly, no fp32 pre-filter constants
+                    // (ws_fqf holds two arrays of B: qf, and behind it the NaN-safe copy the 16 x 16 x 64 form stages)
                     HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
                                                            idx->ws_fqf.as<float4>(), s, gemm_i8 ? idx->ws_q8s1.as<float>() : nullptr,
-                                                           gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr));
+                                                           gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr,
+                                                           gemm_i8 ? idx->ws_fqf.as<float4>() + B : nullptr));
+                    epi.qf16 = gemm_i8 ? idx->ws_fqf.as<float4>() + B : nullptr;
+                }
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (n_ranges > 1 && !gemm_i8) {         // (ranges were planned for the int8 GEMM: the other forms take one launch)
                     Timed t(idx, "count_planes", plane_bytes_per_row * (double)(n - range_row[1]));

@@ -426,6 +426,35 @@ __device__ __forceinline__ int acc16_as_int_here(int token)
     return r;
 }
 
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+
+// byte E of the pair (x, y) = (even nibbles, odd nibbles of a count word's low half, one per byte): nibble e of the word
+template <int E>
+__device__ __forceinline__ float count_of_nibble(uint32_t x, uint32_t y)
+{
+    const uint32_t v = (E & 1) ? y : x;
+    float r;
+    if constexpr ((E >> 1) == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
+    else asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// Pass 1 of this epilogue, round 3.  The test of one (query, row) pair is
+//     upper = a (qx rb_j) + m qz + cjw_j  >=  qy            cjw_j = recency_j + row bound_j + QW eb_j
+// with QW = the LARGEST query-side quantisation term of the batch's (finite) queries instead of the pair's own (eb_j >= 0, so
+// the bound only grows -- by (QW - qw_q) eb_j, nothing for queries quantised alike; pass 2 keeps the pair's own bound in fp64).
+// That makes cjw a per-ROW constant, and the pair's test three packed instructions for two rows (v_pk_mul_f32, two
+// v_pk_fma_f32) plus its share of a v_pk_add_f32 (- qy) and a v_max3_f32 that folds two differences into the running maximum
+// of the group (8 rows x one query per lane): no compare and no scalar OR per pair -- one compare per group.  The match count
+// of a pair comes out of its count word with v_cvt_f32_ubyteN after the word's nibbles were spread to bytes once for four
+// queries.  Round 2's form: 9.3 vector + 1 scalar instruction per pair (3,800 in all per wave and tile); this one: 6.4.
+//
+// NaN: v_max3_f32 drops a NaN operand, so no NaN may stand for "keep".  The inputs are made safe instead: a row whose
+// constants are not finite (embedding with a non-finite value: "never screened out") enters as rb = 0, cjw = +inf (every
+// pair passes), a row past the end as cjw = -inf; launch_fused_query_consts hands over finite qx, qz (and QW) and turns a
+// query with anything non-finite into qx = qz = 0, qy = -inf (every pair passes); a slot without a query has qy = +inf.
+// a is an integer dot (|a| <= 3072 * 127^2), rb <= 1e30 and qx <= 1: no product overflows; inf - inf only arises for pairs
+// that are to be dropped (row past the end and keep-everything query; no query and keep-everything row).
 template <int QDEPTH, typename HOOK = EpiNoHook>
 __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                  const FusedEpilogue &epi, int lane, EpiParked *queue, int queue_stride, uint32_t idx_salt,
@@ -435,19 +464,22 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
 #define ORR_EPI_STAMP(k) if (st && lane == 0) st[k] = __builtin_amdgcn_s_memtime()
     const int c = tile16_c_of(lane), g = tile16_g_of(lane);
     const int sh = 16 * (g & 1);
-    float rb[8], cj[8], eb[8];
+    const float qw_max = qf_lds[0].w;                                       // (the staged constants carry QW in every .w: launch_fused_query_consts)
+    f32x2e rb2[4], cjw2[4];
     const int64_t col0 = colbase + c;                                      // this lane's row of row tile 0 (tile j: + 16 j)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        rb[j] = (float)L.rc[j].x * L.rf[j].x;                              // the accumulator is the integer dot
-        const float rr = col0 + j * 16 < n_rows ? (float)L.rc[j].y : -__builtin_huge_valf();   // rows past the end never pass
-        cj[j] = rr + L.rf[j].y;
-        eb[j] = L.rf[j].z;
+        const float rbv = (float)L.rc[j].x * L.rf[j].x;                     // the accumulator is the integer dot
+        const float cj = (float)L.rc[j].y + L.rf[j].y, eb = L.rf[j].z;
+        const bool keep_all = !(rbv <= 1e30f) || !(eb <= 1e30f) || !(cj <= 3.0e38f) || !(cj >= -3.0e38f);     // (also true for NaNs)
+        const float cjw = keep_all ? __builtin_huge_valf() : __builtin_fmaf(qw_max, eb, cj);
+        rb2[j >> 1][j & 1] = keep_all ? 0.f : rbv;
+        cjw2[j >> 1][j & 1] = col0 + j * 16 < n_rows ? cjw : -__builtin_huge_valf();   // rows past the end never pass
     }
-    if (st) { asm volatile("" :: "v"(cj[0]), "v"(rb[0]), "v"(eb[0])); ORR_EPI_STAMP(4); }
+    if (st) { asm volatile("" :: "v"(cjw2[0][0]), "v"(rb2[0][0])); ORR_EPI_STAMP(4); }
     int parked = 0;
     const float4 *qf_lane = qf_lds + 4 * g;                                // query 16 t + 4 g + e of block b: qf_lane[32 b + 16 t + e]
-    // Pass 1a for all four blocks first, pass 1b (rare, and twenty times the code) for the flagged blocks behind them: with
+    // Pass 1a for all four blocks first, pass 1b (rare, and twenty times the code) for the flagged groups behind them: with
     // 1b's code between the blocks' 1a, every block began with a jump over 21 KiB and a cold instruction cache (6,500 cycles
     // per output tile by the stamps; the accumulators stay where they are, so 1b can read them again later).
     // What 1a hands to 1b: one bit per (block, group of 8 rows x one query per lane) -- 1b then runs for the flagged GROUPS only
@@ -457,32 +489,40 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
     static_for<4>([&](auto b_c) {
         constexpr int b = decltype(b_c)::value;
         between_blocks(b);
-        uint32_t w[8][2];
+        static_for<2>([&](auto t_c) {
+            constexpr int t = decltype(t_c)::value;
+            // this lane's four queries of tile (2 b + t), splatted for the packed instructions
+            f32x2e qx2[4], qz2[4], nqy2[4];
+            float mx[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { w[j][0] = L.w[b][j][0] >> sh; w[j][1] = L.w[b][j][1] >> sh; }
-        // Pass 1a, branch-free (see fused_epilogue): could any of the block's 8 x 8 elements of any lane reach its query's floor?
-        float4 qf = qf_lane[32 * b];
-        static_for<8>([&](auto te_c) {
-            constexpr int te = decltype(te_c)::value, t = te >> 2, e = te & 3;
-            constexpr int nxt = te + 1 < 8 ? 16 * ((te + 1) >> 2) + ((te + 1) & 3) : 0;
-            const float4 qf_next = qf_lane[32 * b + nxt];
-            unsigned long long hit[8];                                      // (OR-ed after the group: see fused_epilogue)
-            static_for<8>([&](auto j_c) {
-                constexpr int j = decltype(j_c)::value;
-                const uint32_t m = (w[j][t] >> (4 * e)) & 15u;
-                const float a = acc16_as_float<4 * (8 * (2 * b + t) + j) + e>(acc_token);
-                const float upper = __builtin_fmaf((float)m, qf.z, __builtin_fmaf(a, qf.x * rb[j], __builtin_fmaf(qf.w, eb[j], cj[j])));
-                hit[j] = __builtin_amdgcn_ballot_w64(!(upper < qf.y));
+            for (int e = 0; e < 4; ++e) {
+                const float4 qf = qf_lane[32 * b + 16 * t + e];
+                qx2[e] = f32x2e{qf.x, qf.x}; qz2[e] = f32x2e{qf.z, qf.z}; nqy2[e] = f32x2e{-qf.y, -qf.y};
+                mx[e] = -__builtin_huge_valf();
+            }
+            static_for<4>([&](auto jp_c) {
+                constexpr int jp = decltype(jp_c)::value, j0 = 2 * jp;
+                // the count words of rows j0, j0 + 1: nibble e -> byte (e >> 1) of x (even e) or y (odd e)
+                const uint32_t w0 = L.w[b][j0][t] >> sh, w1 = L.w[b][j0 + 1][t] >> sh;
+                const uint32_t x0 = w0 & 0x0F0F0F0Fu, y0 = (w0 >> 4) & 0x0F0F0F0Fu, x1 = w1 & 0x0F0F0F0Fu, y1 = (w1 >> 4) & 0x0F0F0F0Fu;
+                static_for<4>([&](auto e_c) {
+                    constexpr int e = decltype(e_c)::value;
+                    const f32x2e a2 = {acc16_as_float<4 * (8 * (2 * b + t) + j0) + e>(acc_token), acc16_as_float<4 * (8 * (2 * b + t) + j0 + 1) + e>(acc_token)};
+                    const f32x2e m2 = {count_of_nibble<e>(x0, y0), count_of_nibble<e>(x1, y1)};
+                    const f32x2e t1 = a2 * rb2[jp];
+                    const f32x2e t2 = __builtin_elementwise_fma(t1, qx2[e], cjw2[jp]);
+                    const f32x2e t3 = __builtin_elementwise_fma(m2, qz2[e], t2);
+                    const f32x2e d = t3 + nqy2[e];
+                    mx[e] = __builtin_fmaxf(__builtin_fmaxf(mx[e], d[0]), d[1]);
+                });
             });
-            unsigned long long group_any = hit[0];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) group_any |= hit[j];
-            group_flags |= group_any != 0ull ? 1u << (8 * b + te) : 0u;
-            // (pinned: the flags are only looked at behind all four blocks, and left alone the compiler postpones the ORs to
-            // there -- parking all 256 masks in vector-register lanes meanwhile and fetching them back one v_readlane at a
-            // time, 7,000 cycles per tile)
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long group_any = __builtin_amdgcn_ballot_w64(mx[e] >= 0.f);
+                group_flags |= group_any != 0ull ? 1u << (8 * b + 4 * t + e) : 0u;
+            }
+            // (pinned: the flags are only looked at behind all four blocks; left alone the compiler postpones the ORs)
             asm volatile("" :: "s"(group_flags));
-            qf = qf_next;
         });
         if constexpr (b == 0) { ORR_EPI_STAMP(5); }
     });
@@ -491,7 +531,7 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
     static_for<4>([&](auto b_c) {
         constexpr int b = decltype(b_c)::value;
         if (((group_flags >> (8 * b)) & 0xffu) != 0u) {
-            // Pass 1b: the same tests element by element, parking what passes (about one block in fifteen, one group of it).
+            // Pass 1b: the same test element by element, parking what passes (about one block in fifteen, one group of it).
             // Its count words come from memory again: kept in registers since pass 1a they were 64 more live values for a rare
             // path.
             uint32_t at1[8], w1[8][2];
@@ -507,7 +547,7 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
                     constexpr int j = decltype(j_c)::value;
                     const uint32_t m = ((w1[j][t] >> sh) >> (4 * e)) & 15u;
                     const float a = acc16_as_float_here<4 * (8 * i + j) + e>(token_1b);
-                    const float upper = __builtin_fmaf((float)m, q1.z, __builtin_fmaf(a, q1.x * rb[j], __builtin_fmaf(q1.w, eb[j], cj[j])));
+                    const float upper = __builtin_fmaf((float)m, q1.z, __builtin_fmaf(a * rb2[j >> 1][j & 1], q1.x, cjw2[j >> 1][j & 1]));
                     const bool drop = upper < q1.y || !has_query || !(col0 + j * 16 < n_rows);
                     if (!drop) {
                         if (parked < QDEPTH) {

@@ -349,20 +349,14 @@ hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64
 }
 
 // qf[b] = {0.7 / sqrt(normA) in fp32 (0 without cosine), floor score - margin, keyword credit per match, 0}
-__global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryConst *__restrict__ qc,
-                                                                 const unsigned long long *__restrict__ tau, int32_t B,
-                                                                 float4 *__restrict__ qf, const float *__restrict__ i8_qs1,
-                                                                 const double *__restrict__ i8_qerr2)
+__device__ __forceinline__ float4 fused_query_const_of(const QueryConst &c, unsigned long long tau_b, const float *i8_qs1, const double *i8_qerr2, int b)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const QueryConst c = qc[b];
     float4 o;
     o.x = c.use_cos ? (float)(c.inv_sqrt_na * 0.7) : 0.f;
-    if (tau[b] <= 1ull) {
+    if (tau_b <= 1ull) {
         o.y = -__builtin_huge_valf();                       // no floor (or a NaN floor): everything is tested exactly
     } else {
-        const double floor_score = key_score(tau[b]);
+        const double floor_score = key_score(tau_b);
         // fp32 evaluation of cos*0.7 + kw*0.2 + rec*0.1 is off by < 1e-6 for scores of magnitude <= 1; 1e-5
         // margin, scaled up for larger magnitudes, and rounded down
         const double margin = 1e-5 * (1.0 + fabs(floor_score));
@@ -375,14 +369,43 @@ __global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryCons
         o.x *= i8_qs1[b];
         o.w = c.use_cos ? __double2float_ru(0.7 * 1.000001 * sqrt(i8_qerr2[b]) * c.inv_sqrt_na) : 0.f;
     }
-    qf[b] = o;
+    return o;
+}
+
+// ONE workgroup: the batch's largest (finite) query bound term is part of qf16.
+__global__ __launch_bounds__(256) void fused_query_consts_kernel(const QueryConst *__restrict__ qc,
+                                                                 const unsigned long long *__restrict__ tau, int32_t B,
+                                                                 float4 *__restrict__ qf, const float *__restrict__ i8_qs1,
+                                                                 const double *__restrict__ i8_qerr2, float4 *__restrict__ qf16)
+{
+    __shared__ float red[4];
+    float wmax = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float4 o = fused_query_const_of(qc[b], tau[b], i8_qs1, i8_qerr2, b);
+        qf[b] = o;
+        const bool fin = o.x >= 0.f && o.x <= 1.0f && o.w >= 0.f && o.w <= 1e30f && o.z >= 0.f && o.z <= 1.f && o.y == o.y;
+        if (fin) wmax = fmaxf(wmax, o.w);
+    }
+    if (!qf16) return;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
+    __syncthreads();
+    wmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float4 o = fused_query_const_of(qc[b], tau[b], i8_qs1, i8_qerr2, b);
+        const bool fin = o.x >= 0.f && o.x <= 1.0f && o.w >= 0.f && o.w <= 1e30f && o.z >= 0.f && o.z <= 1.f && o.y == o.y;
+        if (!fin) { o.x = 0.f; o.y = -__builtin_huge_valf(); o.z = 0.f; }      // every pair of this query passes the pre-filter (tested exactly in pass 2)
+        o.w = wmax;
+        qf16[b] = o;
+    }
 }
 
 hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s,
-                                     const float *i8_qs1, const double *i8_qerr2)
+                                     const float *i8_qs1, const double *i8_qerr2, float4 *qf16)
 {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fused_query_consts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, qc, tau, B, qf, i8_qs1, i8_qerr2);
+    hipLaunchKernelGGL(fused_query_consts_kernel, dim3(1), dim3(256), 0, s, qc, tau, B, qf, i8_qs1, i8_qerr2, qf16);
     return hipGetLastError();
 }
 

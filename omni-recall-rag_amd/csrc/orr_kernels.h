@@ -197,6 +197,7 @@ struct FusedEpilogue {
     SelEntry *buf;                     // [B][cap]
     uint32_t cap;
     unsigned long long *stamps;        // diagnostic (ORR_SCREEN_STAMPS=file): s_memtime at the phases of every output tile, else null
+    const float4 *qf16;                // [B] the 16 x 16 x 64 form's staged constants: qf with everything finite and .w = the batch's largest query bound term (launch_fused_query_consts)
     uint32_t *tickets;                 // [8] zeroed counters of ONE launch of the 16 x 16 x 64 screening GEMM (output tiles beyond a workgroup's first two are drawn from them), or null: static assignment
 };
 // K2b: S (or the fused epilogue) from three bf16 MFMA products of hi/lo splits (see orr_gemm.hip
@@ -207,8 +208,11 @@ hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float
 // rows [row_first, row_end) only (row_first % 256 == 0; row_end < 0: to the end)
 hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s,
                                      int64_t row_first = 0, int64_t row_end = -1);
+// qf16 (optional, [B]): the same constants made safe for a NaN-dropping test (fused_epilogue16) -- finite qx / qz, a query with
+// anything non-finite turned into "every pair passes" (qx = qz = 0, floor -inf) -- with .w = the largest finite query bound
+// term of the batch in EVERY entry.
 hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s,
-                                     const float *i8_qs1 = nullptr, const double *i8_qerr2 = nullptr);
+                                     const float *i8_qs1 = nullptr, const double *i8_qerr2 = nullptr, float4 *qf16 = nullptr);
 // K2c (orr_screen.hip): plain-bf16 screening GEMM (256 x 256 x 64 tiles, LDS-DMA staging) over TILED bf16
 // images of the embeddings (the shard's shadow) and of the batch's queries; S or the fused epilogue as above.
 size_t bf16_tiled_bytes(int64_t n_rows, int32_t D);

@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
                               "+s"(ep.i8_rowf), "+s"(ep.i8_qs1), "+s"(ep.cnt), "+s"(ep.buf));
             asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
             const int q = b0 + tid;
-            qf_mine = load_global(ep.qf, (uint32_t)(q < B ? q : B - 1));
+            qf_mine = load_global(ep.qf16, (uint32_t)(q < B ? q : B - 1));      // (the NaN-safe constants with the batch's QW in .w)
             epilogue_issue_loads16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);
         }
     };
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
     } else {
         uint32_t salt = 0;
         asm volatile("" : "+s"(salt));
-        if (b0 + tid >= B) qf_mine = make_float4(0.f, __builtin_huge_valf(), 0.f, 0.f);    // no query: floor +inf
+        if (b0 + tid >= B) qf_mine = make_float4(0.f, __builtin_huge_valf(), 0.f, qf_mine.w);    // no query: floor +inf (.w: the batch's QW, as in every entry)
         EpiParked *queue = reinterpret_cast<EpiParked *>(lds_epi) + tid;
         float4 *qf_lds = reinterpret_cast<float4 *>(lds_epi + kS4Queue * 8 * 256);
         qf_lds[tid] = qf_mine;
@@ -1480,7 +1480,8 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
         // 129+ queries: the tile on 16 x 16 x 64 MFMAs, unless the shard is so large that its epilogue's 32-bit word offsets
         // inside a pair of count planes would not do (then the 32 x 32 x 32 form).  Measured on one box, eight-wave form long
         // gone: 1M x 3072 rows x 256 queries 0.89 -> 0.85 ms, x 1024: 3.23 -> 2.92 ms; C3 (4 launches) 2.23 -> 2.13 ms each.
-        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30) && n_rows < ((int64_t)1 << 28) && D / 64 > kS4NB;
+        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30) && n_rows < ((int64_t)1 << 28) && D / 64 > kS4NB &&
+                            epi.qf16 != nullptr;
         if (tile16 && B > 256) ORR_LAUNCH_I8W16(false);
         else if (tile16 && B > 128) ORR_LAUNCH_I8W16(true);
         else if (B > 256) ORR_LAUNCH_I8W4(8, false);
