@@ -70,6 +70,13 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of a multi-GPU run: nccl (= RCCL, the product path) or gloo (a rehearsal of the same "
                          "code with several ranks on ONE card, which RCCL refuses; ranks then share cuda:0)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "cluster"],
+                    help="several GPUs: 'ranks' = one process per GPU + RCCL (torch.distributed; what the driver launches); 'cluster' = ONE "
+                         "process driving all --gpus devices through orr_cluster_search_batch (the form a C# host loads, INTEGRATION.md 5a)")
+    ap.add_argument("--cluster-oversubscribe", action="store_true",
+                    help="rehearsal only: --mode cluster with more shards than visible devices (shards share cards, device g %% visible)")
+    ap.add_argument("--strong-rows", type=int, default=10_000_000, help="total rows of the fixed-N (strong-scaling) leg of a multi-GPU run; 0 = skip")
+    ap.add_argument("--cluster-leg-rows", type=int, default=1_000_000, help="rows per device of the in-process orr_cluster leg of a multi-GPU run; 0 = skip")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="orr_index_set_option on every shard before the run (e.g. two_stage=0)")
     return ap.parse_args(argv)
@@ -243,8 +250,7 @@ def run_leg(leg, args, env, idx, front, gen, overlap=False):
         import threading
         lane2 = None
         try:
-            lane2 = idx.view()
-            both = [idx, lane2]
+            both = [idx, idx]                    # ONE handle from two threads: the library gives each search a lane of its own
             errors = []
 
             def run2(lane):
@@ -450,6 +456,56 @@ def oracle_leg(args, env, idx, gen, n_total, B_headline, probe):
 
 
 
+def run_cluster_leg(args, env, gen, devices, rows_per_dev, B, terms=True, workload=None):
+    """ONE process, every device: orr_cluster (one shard per device, a host thread per shard, records through pinned host
+    memory, host merge) -- the multi-GPU form of the C ABI that a C# host binds.  Queries are host-resident by contract."""
+    P, torch = env["P"], env["torch"]
+    G, dim, k = len(devices), args.dim, args.topk
+    n_total = rows_per_dev * G
+    t0 = time.perf_counter()
+    cl = P.RecallCluster(devices, dim, capacity_rows_per_shard=rows_per_dev)
+    step = 32768
+    for g, d in enumerate(devices):
+        dev = torch.device("cuda", d)
+        sh = cl.shard(g)
+        with torch.cuda.device(dev):
+            for r0 in range(0, rows_per_dev, step):
+                m = min(step, rows_per_dev - r0)
+                g0 = g * rows_per_dev + r0
+                pool, off = gen.contents(g0, m, dev)
+                emb = gen.embeddings(g0, m, dim, dev)
+                created = gen.created_ticks(g0, m, n_total, dev)
+                ids = torch.arange(g0, g0 + m, dtype=torch.int64, device=dev)
+                torch.cuda.current_stream().synchronize()
+                sh.append(emb, created, pool, off, row_ids=ids)
+    cl.seal()
+    setup = time.perf_counter() - t0
+    n_steps_total = args.warmup + args.steps
+    q_steps, term_steps = [], []
+    for s_ in range(n_steps_total):
+        b0 = s_ * B
+        q_steps.append(gen.query_vectors(b0, B, dim, n_total, "cpu").numpy())
+        texts = gen.query_texts(b0, B, n_total)
+        term_steps.append(P.PackedTerms(P.pack_terms([P.text.query_terms(t) if terms else [] for t in texts])))
+    for s_ in range(args.warmup):
+        cl.search(q_steps[s_], term_steps[s_], gen.NOW_TICKS, k, candidate_limit=n_total)
+    cl.search_stats(reset=True)
+    t1 = time.perf_counter()
+    last = None
+    for s_ in range(args.warmup, n_steps_total):
+        last = cl.search(q_steps[s_], term_steps[s_], gen.NOW_TICKS, k, candidate_limit=n_total)
+    dt = time.perf_counter() - t1
+    planted = gen.planted_rows((n_steps_total - 1) * B, B, n_total)
+    res = {"workload": workload or ("orr_cluster (one process, %d devices): %d chunks x %d-d, %d per device, batch=%d, top-k=%d, %s" %
+                                    (G, n_total, dim, rows_per_dev, B, k, "full hybrid" if terms else "cosine + recency")),
+           "value": args.steps * B / dt, "unit": "queries/s", "ms_per_step": 1e3 * dt / args.steps, "queries_per_step": B,
+           "corpus_rows": n_total, "devices": G, "rank1_is_planted_row": [int(r) for r in last[0][:, 0]] == planted,
+           "search_stats": cl.search_stats(), "setup_s": round(setup, 2),
+           "exchange": "per-shard [B][k'+1] candidate records through pinned host memory, host merge (no collective: one address space)"}
+    cl.close()
+    return res
+
+
 # ------------------------------------------------------------------------------------------------
 # the driver's record: ONE short last line on stdout; the whole document goes to a file
 # ------------------------------------------------------------------------------------------------
@@ -501,6 +557,8 @@ def compact_line(out, full_path=None):
             c[k] = _r(out[k])
     if isinstance(out.get("two_steps_in_flight"), dict) and "value" in out["two_steps_in_flight"]:
         c["two_in_flight_qps"] = _r(out["two_steps_in_flight"]["value"])
+    if out.get("leg_errors"):
+        c["leg_errors"] = {kk: str(v)[:80] for kk, v in out["leg_errors"].items()}
     ss = out.get("search_stats") or {}
     if ss:
         c["search_stats"] = _pick(ss, ("passes", "requeried", "overflowed_queries", "exact_pass_queries", "survivors_per_query", "pass_mode"))
@@ -517,7 +575,7 @@ def compact_line(out, full_path=None):
     if full_path:
         c["full"] = full_path
     # shrink in a fixed order if needed; the contract keys stay
-    for drop in ("legs_qps_ms_kernelms_frac", "search_stats", "two_in_flight_qps", "full"):
+    for drop in ("legs_qps_ms_kernelms_frac", "search_stats", "two_in_flight_qps", "leg_errors", "full"):
         if len(json.dumps(c, separators=(",", ":"))) <= COMPACT_LIMIT:
             break
         c.pop(drop, None)
@@ -549,16 +607,43 @@ def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     launched = "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not launched:
+    if args.gpus > 1 and args.mode == "ranks" and not launched:
         spawn_ranks(args, argv)                    # never returns
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    cluster_mode = args.gpus > 1 and args.mode == "cluster"
+    world = 1 if cluster_mode else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if cluster_mode else int(os.environ.get("RANK", "0"))
+    if not cluster_mode and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     probe = host_probe() if rank == 0 else {}      # child processes only; before the first GPU call of this process
-    t_start = time.perf_counter()
+    state = {"t_start": time.perf_counter(), "out": None, "dist": None}
+    try:
+        run(args, probe, state, cluster_mode, world, rank)
+    except BaseException as exc:                   # a collective that raised, a rank that died, no memory: say so in the ONE line
+        if isinstance(exc, SystemExit) and exc.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            out = state["out"] or {
+                "metric": METRIC, "value": None, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+                "config": {"workload": "not reached"}, "roofline": None, "cpu_baseline": None}
+            out["error"] = ("%s: %s" % (type(exc).__name__, exc))[:400]
+            out["total_s"] = round(time.perf_counter() - state["t_start"], 2)
+            emit(out)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)                                # (no destructor of a half-dead process group gets to hang the job)
 
+
+METRIC = "queries/sec at top-k=10 over N x 3072-d chunks; score delta vs C# reference in `parity`"
+DTYPE = "i8 screen + f32*f32->f64 exact re-score"
+
+
+def run(args, probe, state, cluster_mode, world, rank):
+    t_start = state["t_start"]
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not cluster_mode else 0
+    import datetime
     import torch
     import torch.distributed as dist
     import __graft_entry__ as graft
@@ -566,22 +651,53 @@ def main():
     syn = importlib.import_module(graft.PKG_NAME + ".synthetic")
     sharded = importlib.import_module(graft.PKG_NAME + ".sharded")
     n_visible = torch.cuda.device_count()
+    if cluster_mode and n_visible < args.gpus and not args.cluster_oversubscribe:
+        raise SystemExit(f"--mode cluster --gpus {args.gpus} needs {args.gpus} visible GPUs, found {n_visible}")
     if world > 1 and args.backend == "nccl" and n_visible < world:
         raise SystemExit(f"--gpus {world} with the nccl (RCCL) backend needs {world} visible GPUs, found {n_visible}")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_visible)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
+        # (a collective that cannot complete -- a rank died -- raises after three minutes instead of the default ten, and the
+        # survivors report it in the JSON line)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+        state["dist"] = dist
     env = {"P": P, "torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank}
 
     dim, k = args.dim, args.topk
     legs_out = {}
     setup_s = {}
-    if world == 1:
+    leg_errors = {}
+
+    def optional_leg(name, fn):
+        """A leg beside the headline must not take the headline down with it: its failure is recorded and the run goes on.
+        (Collective legs: a failure on ONE rank desynchronises the job -- those are not optional and propagate.)"""
+        try:
+            r = fn()
+            if r is not None:
+                legs_out[name] = r
+        except Exception as exc:
+            leg_errors[name] = ("%s: %s" % (type(exc).__name__, exc))[:300]
+
+    if cluster_mode:
+        # ---- ONE process, all devices, through orr_cluster: the C5 per-GPU shape on every device
+        rows = args.rows_per_gpu or 12_500_000
+        B = args.batch or 1024
+        n_total = rows * args.gpus
+        head = run_cluster_leg(args, env, syn, [g % max(1, n_visible) for g in range(args.gpus)], rows, B, terms=not args.no_terms,
+                               workload=workload_label(rows, dim, B, k, not args.no_terms, args.gpus).replace("row-sharded over", "orr_cluster, one process, over"))
+        head["row_scores_per_sec"] = head["value"] * n_total
+        if n_visible < args.gpus:
+            head["workload"] += " [REHEARSAL: %d shards on %d card(s)]" % (args.gpus, n_visible)
+        head["roofline"] = None
+        head["kernels"] = {}
+        head["query_tokenisation_ms_per_step"] = None
+        front, idx = None, None
+    elif world == 1:
         rows = args.rows_per_gpu or 10_000_000
         B = args.batch or 256
         # ---- leg: C2 (configs[1]) on its own 1M-row shard
@@ -620,67 +736,107 @@ def main():
         rows = args.rows_per_gpu or 12_500_000
         B = args.batch or 1024
         n_total = rows * world
+        coll_dev = dev if args.backend == "nccl" else "cpu"
+        # ---- leg: FIXED corpus split over the ranks (strong scaling: the curve 1 -> N shows what sharding buys one batch),
+        # C3's corpus and batch: 10M rows in all, 256 hybrid queries per step.  Built, timed and freed before the headline shard.
+        if not args.no_legs and args.strong_rows >= world:
+            rows_s = args.strong_rows // world
+            t0 = time.perf_counter()
+            idx_s = build_shard(P, syn, torch, rank, rows_s, dim, rows_s * world, dev, args.set_option)
+            setup_s["strong_corpus"] = time.perf_counter() - t0
+            front_s = sharded.ShardedRecallSearch(idx_s, dim, coll_dev)
+            leg = Leg("strong", "fixed corpus (strong scaling): " + workload_label(rows_s, dim, 256, k, True, world), rows_s, rows_s * world, 256)
+            r = run_leg(leg, args, env, idx_s, front_s, syn)
+            r["scaling"] = "strong"
+            r["collectives_per_step"] = front_s.collectives / max(1, args.warmup + args.steps + min(5, args.steps))
+            legs_out[f"strong_{args.strong_rows // 1_000_000}M_rows_total_256_queries"] = r
+            idx_s.close()
+            del idx_s, front_s
+            torch.cuda.empty_cache()
         t0 = time.perf_counter()
         idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
         setup_s["headline_corpus"] = time.perf_counter() - t0
-        front = sharded.ShardedRecallSearch(idx, dim, dev if args.backend == "nccl" else "cpu")
+        front = sharded.ShardedRecallSearch(idx, dim, coll_dev)
         ranks_seen = front.rccl_ranks_seen()
         head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, world), rows, n_total, B, terms=not args.no_terms)
         head = run_leg(head_leg, args, env, idx, front, syn)
         head["rccl_ranks_seen"] = ranks_seen if args.backend == "nccl" else 0
         head["backend"] = args.backend + (" (RCCL over xGMI)" if args.backend == "nccl" else f" (rehearsal: {world} ranks, {n_visible} card(s))")
-        head["collectives_per_step"] = front.collectives / max(1, args.warmup + args.steps)
+        head["collectives_per_step"] = front.collectives / max(1, args.warmup + args.steps + min(5, args.steps))
+        head["escalated_queries"] = front.escalated_queries
+        if rank == 0:                              # the headline is in hand from here on: a later failure still reports it
+            state["out"] = assemble(args, probe, head, {}, setup_s, None, None, rows, n_total, B, world, t_start, leg_errors)
         if not args.no_legs:
             for bq in (1, 256):
                 leg = Leg(f"c4_b{bq}", workload_label(rows, dim, bq, k, False, world), rows, n_total, bq, terms=False)
                 legs_out[f"C4_cosine_only_{bq}_queries"] = run_leg(leg, args, env, idx, front, syn)
+        # ---- leg: the same devices from ONE process through orr_cluster (rank 0 drives every device; the other ranks wait).  Small
+        # shards: every device already holds its rank's 12.5M rows.
+        if not args.no_legs and args.cluster_leg_rows > 0 and args.backend == "nccl":
+            if rank == 0:
+                optional_leg("cluster_one_process_%dM_rows_per_device_256_queries" % max(1, args.cluster_leg_rows // 1_000_000),
+                             lambda: run_cluster_leg(args, env, syn, list(range(world)), args.cluster_leg_rows, 256))
+                torch.cuda.set_device(dev_index)
+            dist.barrier()
 
     cpu = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not cluster_mode and not args.no_cpu_baseline:
         t0 = time.perf_counter()
         cpu, parity = oracle_leg(args, env, idx, syn, n_total, B, probe)
         setup_s["oracle_leg"] = time.perf_counter() - t0
 
     if rank == 0:
-        cfg_name = config_name(rows, dim, B, world, not args.no_terms)
-        out = {
-            "metric": "queries/sec at top-k=10 over N x 3072-d chunks; score delta vs C# reference in `parity`",
-            "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8 screen + f32*f32->f64 exact re-score",
-            "dtype_note": "int8 screen with a rigorous per-pair bound over all rows, then f32 x f32 -> f64 re-score of the survivors in the reference's arithmetic",
-            "data": "synthetic",
-            "config": {"workload": head["workload"], "name": cfg_name, "corpus_rows": n_total, "rows_per_gpu": rows,
-                       "queries_per_step": B, "options": args.set_option, "steps_in_flight": 1,
-                       "parallelism": (f"row-sharded x{world}: broadcast of the batch from rank 0, one all-gather of per-shard top-k' "
-                                       f"records (RCCL), host merge on every rank") if world > 1 else "single GPU"},
-            "row_scores_per_sec": head["row_scores_per_sec"],
-            "rank1_is_planted_row": head["rank1_is_planted_row"],
-            "roofline": head["roofline"],
-            "search_stats": head["search_stats"],
-            "kernels": head["kernels"],
-            "query_tokenisation_ms_per_step": head["query_tokenisation_ms_per_step"],
-            "query_tokenisation": head["query_tokenisation"],
-            "legs": legs_out,
-            "peaks": {"hbm_gbs": HBM_PEAK_GBS, "mfma_i8_tops_dense": MFMA_I8_PEAK_TOPS, "mfma_bf16_tflops_dense": MFMA_BF16_PEAK_TFLOPS,
-                      "source": "MI355X_MICROARCH.md chip-level parameters (spec, dense)", "read_on_this_box": probe.get("gpu")},
-            "setup_s": {kk: round(v, 2) for kk, v in setup_s.items()},
-            "total_s": round(time.perf_counter() - t_start, 2),
-        }
-        for extra in ("rccl_ranks_seen", "collectives_per_step", "backend", "two_steps_in_flight"):
-            if extra in head:
-                out[extra] = head[extra]
-        if parity is not None:
-            out["parity"] = parity
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        elif world == 1:
-            out["cpu_baseline"] = None
+        out = assemble(args, probe, head, legs_out, setup_s, cpu, parity, rows, n_total, B, args.gpus if cluster_mode else world, t_start, leg_errors,
+                       cluster_mode=cluster_mode)
+        state["out"] = out
         emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    idx.close()
+    if idx is not None:
+        idx.close()
+
+
+def assemble(args, probe, head, legs_out, setup_s, cpu, parity, rows, n_total, B, world, t_start, leg_errors, cluster_mode=False):
+    dim = args.dim
+    cfg_name = config_name(rows, dim, B, world, not args.no_terms)
+    out = {
+        "metric": METRIC,
+        "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE,
+        "dtype_note": "int8 screen with a rigorous per-pair bound over all rows, then f32 x f32 -> f64 re-score of the survivors in the reference's arithmetic",
+        "data": "synthetic",
+        "config": {"workload": head["workload"], "name": cfg_name, "corpus_rows": n_total, "rows_per_gpu": rows,
+                   "queries_per_step": B, "options": args.set_option, "steps_in_flight": 1,
+                   "parallelism": ("one process, orr_cluster over %d devices: per-shard top-k' records through pinned host memory, host merge" % world) if cluster_mode
+                   else (f"row-sharded x{world}: broadcast of the batch from rank 0, one all-gather of per-shard top-k' "
+                         f"records (RCCL), host merge on every rank") if world > 1 else "single GPU"},
+        "row_scores_per_sec": head.get("row_scores_per_sec"),
+        "rank1_is_planted_row": head.get("rank1_is_planted_row"),
+        "roofline": head.get("roofline"),
+        "search_stats": head.get("search_stats"),
+        "kernels": head.get("kernels"),
+        "query_tokenisation_ms_per_step": head.get("query_tokenisation_ms_per_step"),
+        "query_tokenisation": head.get("query_tokenisation"),
+        "legs": legs_out,
+        "peaks": {"hbm_gbs": HBM_PEAK_GBS, "mfma_i8_tops_dense": MFMA_I8_PEAK_TOPS, "mfma_bf16_tflops_dense": MFMA_BF16_PEAK_TFLOPS,
+                  "source": "MI355X_MICROARCH.md chip-level parameters (spec, dense)", "read_on_this_box": probe.get("gpu")},
+        "setup_s": {kk: round(v, 2) for kk, v in setup_s.items()},
+        "total_s": round(time.perf_counter() - t_start, 2),
+    }
+    for extra in ("rccl_ranks_seen", "collectives_per_step", "backend", "two_steps_in_flight", "escalated_queries"):
+        if extra in head:
+            out[extra] = head[extra]
+    if leg_errors:
+        out["leg_errors"] = dict(leg_errors)
+    if parity is not None:
+        out["parity"] = parity
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    else:
+        out["cpu_baseline"] = None
+    return out
 
 
 def config_name(rows, dim, B, world, terms):

@@ -26,8 +26,12 @@
  *     hipMemcpyDefault.  The library works on its own non-blocking HIP streams: device-resident
  *     inputs must be COMPLETE (their producing stream synchronised, or an event waited for)
  *     before the call, and device-resident outputs are complete when the call returns.
- *   - threads: searches on a sealed index may be issued from any thread (they
- *     are serialised per index in this version); append / seal are exclusive.
+ *   - threads: searches on a sealed index may be issued from any thread and run CONCURRENTLY on one
+ *     handle (RecallSearchService is scoped per request, Program.cs:59; the store behind it is
+ *     lock-free, InMemoryIngestionStore.cs:8-9): each takes a search lane of the index -- its own
+ *     workspaces, or those of an internal view created on demand, up to the "max_lanes" option
+ *     (default 4; corpus and shadows are shared, a lane costs its workspaces); further callers wait
+ *     for a lane.  append / seal / delete / options wait until no search is in flight.
  */
 #ifndef OMNIRECALL_HIP_H
 #define OMNIRECALL_HIP_H
@@ -264,6 +268,8 @@ int64_t orr_index_live_rows(const orr_index *idx);
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "dead_rows_before"  deleted rows in the shards in front of this one (default 0), see above.
+ *   "max_lanes"      1..16 (default 4): searches that may run at once on this handle (see "threads" above); lanes that
+ *                    exist are kept.
  *   "kw_hits_cap"    entries of the keyword chain's hit list, one per (distinct query term, vocabulary token containing it)
  *                    (default 16M = 384 MB at most).  A batch that needs more grows the list to the measured count and
  *                    repeats its pass; the option exists to pre-size it (or, in tests, to force that path).
@@ -329,7 +335,8 @@ int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset)
  *   search_batch      arguments as orr_search_batch; q must be HOST memory (each device uploads it).  Row ids are
  *                     the ids given at append (default: position in the shard + its row_base at append time, i.e.
  *                     pass explicit row_ids when appending to a cluster).
- * Not thread-safe against itself: one search at a time per cluster (searches on different clusters are independent). */
+ * Thread-safe: cluster searches from different threads run side by side (each shard half on a search lane of its shard,
+ * host halves on persistent pool threads); seal and destroy are exclusive. */
 typedef struct orr_cluster orr_cluster;
 int        orr_cluster_create(const int32_t *devices, int32_t n_shards, int32_t dim, int64_t capacity_rows_per_shard,
                               orr_cluster **out);

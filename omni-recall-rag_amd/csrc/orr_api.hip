@@ -20,6 +20,8 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <shared_mutex>
+#include <deque>
 #include <new>
 #include <numeric>
 #include <string>
@@ -196,6 +198,19 @@ struct orr_index {
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm, pin_cnt, pin_kwcnt;
     hipEvent_t ev_q = nullptr;
 
+    // search lanes (owning index only): concurrent searches on ONE handle each take a lane -- the index itself, or one of up
+    // to max_lanes - 1 internal views (own streams and workspaces, shared corpus and shadows) created when first needed
+    std::mutex lanes_mu;
+    std::condition_variable lanes_cv;
+    std::vector<orr_index *> lanes;        // internal views (lane 0 is the index itself)
+    std::vector<char> lane_busy;           // [1 + lanes.size()]; a reserved slot whose view is still being made counts as busy
+    bool self_busy = false;
+    int lanes_reserved = 0;                // views being created right now
+    int max_lanes = 4;
+    bool internal_lane = false;            // this view belongs to its parent's lane pool (not handed to the caller)
+    int64_t dead_before_pub = 0, dead_count_pub = 0;   // (under lanes_mu) copies of dead_before / dead.size() a cluster reads without waiting for searches
+    uint32_t survivor_cap_hint = 0;        // (under lanes_mu) a lane measured that the survivors' buffers must be at least this large
+
     // profiling
     int profiling = 0;                     // 0 off, 1 every kernel, 2 only the pass over all rows (the kernel a roofline is quoted on)
     std::vector<KernelStat> stats;
@@ -203,7 +218,104 @@ struct orr_index {
     std::vector<hipEvent_t> event_pool;
 };
 
+extern "C" int orr_index_view(orr_index *parent, orr_index **view);
+
 namespace {
+
+// ---- search lanes ------------------------------------------------------------------------------------------------
+// The request path is concurrent by nature (RecallSearchService is scoped, one instance per request, Program.cs:59; the store
+// behind it is lock-free, InMemoryIngestionStore.cs:8-9).  A search on an OWNING index takes a free lane: the index's own
+// workspaces, or those of an internal view (created on demand, at most max_lanes - 1 of them; corpus and shadows are shared,
+// nothing is copied).  Searches from different threads on one handle then run side by side; the caller never sees a view.
+// A view handle the caller made itself (orr_index_view) is its own single lane, as before.
+struct Lane {
+    orr_index *owner = nullptr;
+    orr_index *lane = nullptr;
+    int slot = -1;                                     // 0: the index itself; i >= 1: owner->lanes[i - 1]
+    Lane() = default;
+    Lane(const Lane &) = delete;
+    Lane &operator=(const Lane &) = delete;
+    Lane(Lane &&o) noexcept : owner(o.owner), lane(o.lane), slot(o.slot) { o.owner = nullptr; o.lane = nullptr; o.slot = -1; }
+    int acquire(orr_index *idx)
+    {
+        if (idx->is_view) { lane = idx; return ORR_OK; }
+        owner = idx;
+        std::unique_lock<std::mutex> lk(idx->lanes_mu);
+        for (;;) {
+            auto take = [&](orr_index *l, int sl) {
+                slot = sl; lane = l;
+                if (idx->survivor_cap_hint > l->survivor_cap) l->survivor_cap = idx->survivor_cap_hint;   // what another lane measured
+                return ORR_OK;
+            };
+            if (!idx->self_busy) { idx->self_busy = true; return take(idx, 0); }
+            for (size_t i = 0; i < idx->lanes.size(); ++i)
+                if (idx->lanes[i] && !idx->lane_busy[i]) { idx->lane_busy[i] = 1; return take(idx->lanes[i], (int)i + 1); }
+            if (idx->sealed && (int)idx->lanes.size() + 1 < idx->max_lanes) {
+                const size_t i = idx->lanes.size();
+                idx->lanes.push_back(nullptr);                     // the slot is reserved (and busy) while its view is made
+                idx->lane_busy.push_back(1);
+                lk.unlock();
+                orr_index *v = nullptr;
+                const int r = orr_index_view(idx, &v);             // (waits for the search that holds the index's own lane)
+                lk.lock();
+                if (r == ORR_OK) {
+                    v->internal_lane = true;
+                    idx->lanes[i] = v; slot = (int)i + 1; lane = v;
+                    return ORR_OK;
+                }
+                // no room for another set of workspaces (or the index is being torn down): make do with the lanes there are
+                idx->lane_busy[i] = 0;
+                idx->max_lanes = 1;
+                for (orr_index *l : idx->lanes) if (l) ++idx->max_lanes;
+                continue;
+            }
+            idx->lanes_cv.wait(lk);
+        }
+    }
+    void release()
+    {
+        if (!owner) { lane = nullptr; return; }
+        {
+            std::lock_guard<std::mutex> lk(owner->lanes_mu);
+            if (slot == 0) owner->self_busy = false;
+            else if (slot > 0) owner->lane_busy[(size_t)slot - 1] = 0;
+        }
+        owner->lanes_cv.notify_all();
+        owner = nullptr; lane = nullptr; slot = -1;
+    }
+    ~Lane() { release(); }
+};
+
+// Everything that changes what the lanes share or reads their counters (deletes, options, statistics, save, destroy) waits until
+// no search is in flight on any lane and keeps new ones out meanwhile.
+struct AllLanes {
+    orr_index *owner = nullptr;
+    explicit AllLanes(orr_index *idx)
+    {
+        if (!idx || idx->is_view) return;
+        owner = idx;
+        std::unique_lock<std::mutex> lk(idx->lanes_mu);
+        idx->lanes_cv.wait(lk, [idx] {
+            if (idx->self_busy) return false;
+            for (size_t i = 0; i < idx->lanes.size(); ++i) if (idx->lane_busy[i]) return false;
+            return true;
+        });
+        idx->self_busy = true;
+        for (size_t i = 0; i < idx->lanes.size(); ++i) idx->lane_busy[i] = 1;
+    }
+    ~AllLanes()
+    {
+        if (!owner) return;
+        {
+            std::lock_guard<std::mutex> lk(owner->lanes_mu);
+            owner->self_busy = false;
+            for (size_t i = 0; i < owner->lanes.size(); ++i) owner->lane_busy[i] = 0;
+        }
+        owner->lanes_cv.notify_all();
+    }
+    AllLanes(const AllLanes &) = delete;
+    AllLanes &operator=(const AllLanes &) = delete;
+};
 
 int stat_slot(orr_index *idx, const char *name)
 {
@@ -561,6 +673,16 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
 void orr_index_destroy(orr_index *idx)
 {
     if (!idx) return;
+    if (!idx->is_view) {                               // the internal lanes go first (they borrow the corpus)
+        std::vector<orr_index *> lanes;
+        {
+            AllLanes all(idx);
+            lanes.swap(idx->lanes);
+            idx->lane_busy.clear();
+            idx->max_lanes = 1;
+        }
+        for (orr_index *l : lanes) if (l) orr_index_destroy(l);
+    }
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->stream_kw) (void)hipStreamSynchronize(idx->stream_kw);
@@ -607,8 +729,10 @@ void orr_index_destroy(orr_index *idx)
 int orr_index_set_row_base(orr_index *idx, int64_t row_base)
 {
     if (!idx || row_base < 0) return fail(ORR_EINVAL, "orr_index_set_row_base: bad argument");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
     idx->row_base = row_base;
+    for (orr_index *l : idx->lanes) if (l) l->row_base = row_base;
     return ORR_OK;
 }
 
@@ -842,6 +966,7 @@ int read_device_array(FILE *f, void *dptr, size_t bytes, std::vector<uint8_t> &b
 int orr_index_save(orr_index *idx, const char *path)
 {
     if (!idx || !path) return fail(ORR_EINVAL, "orr_index_save: null argument");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
     if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_save: index is not sealed");
     if (idx->is_view) return fail(ORR_ESTATE, "orr_index_save: save the owning index, not a view");
@@ -977,6 +1102,7 @@ int orr_index_load(const orr_config *cfg, const char *path, orr_index **out)
                     return fail(ORR_EINVAL, "shard file has a malformed deleted-row list");
             ORR_TRY(idx->d_dead.reserve(sizeof(int64_t) * idx->dead.size()));
             HIP_TRY(hipMemcpy(idx->d_dead.p, idx->dead.data(), sizeof(int64_t) * idx->dead.size(), hipMemcpyHostToDevice));
+            idx->dead_count_pub = (int64_t)idx->dead.size();
         }
         return ORR_OK;
     };
@@ -1083,6 +1209,7 @@ int orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int
 {
     if (out_deleted) *out_deleted = 0;
     if (!idx || n < 0 || (n > 0 && !row_ids)) return fail(ORR_EINVAL, "orr_index_delete_rows: bad argument");
+    AllLanes all(idx);                                 // no search in flight on any lane while the rows change
     std::lock_guard<std::mutex> lock(idx->mu);
     if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_delete_rows: the index is not sealed");
     if (idx->is_view) return fail(ORR_EINVAL, "orr_index_delete_rows: delete on the owning index, not on a view");
@@ -1124,6 +1251,7 @@ int orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int
     ORR_TRY(idx->d_dead.reserve(sizeof(int64_t) * merged.size()));
     HIP_TRY(hipMemcpy(idx->d_dead.p, merged.data(), sizeof(int64_t) * merged.size(), hipMemcpyHostToDevice));
     idx->dead.swap(merged);
+    { std::lock_guard<std::mutex> pl(idx->lanes_mu); idx->dead_count_pub = (int64_t)idx->dead.size(); }
     if (out_deleted) *out_deleted = (int64_t)fresh.size();
     return ORR_OK;
 }
@@ -1131,26 +1259,35 @@ int orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
 {
     if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
+    AllLanes all(idx);                                 // options apply to every lane of the index
     std::lock_guard<std::mutex> lock(idx->mu);
-    if (strcmp(name, "fuse_epilogue") == 0) { idx->opt_fuse_epilogue = value != 0; return ORR_OK; }
+    auto lanes = [&](auto &&fn) { fn(idx); for (orr_index *l : idx->lanes) if (l) fn(l); };
+    if (strcmp(name, "fuse_epilogue") == 0) { lanes([&](orr_index *x) { x->opt_fuse_epilogue = value != 0; }); return ORR_OK; }
     if (strcmp(name, "dead_rows_before") == 0) {
         if (value < 0) return fail(ORR_EINVAL, "orr_index_set_option: dead_rows_before must be >= 0");
-        idx->dead_before = value;
+        lanes([&](orr_index *x) { x->dead_before = value; });
+        { std::lock_guard<std::mutex> pl(idx->lanes_mu); idx->dead_before_pub = value; }
         return ORR_OK;
     }
     if (strcmp(name, "kw_hits_cap") == 0) {
         if (value < 1 || value > (int64_t)0x7FFFFFFF) return fail(ORR_EINVAL, "orr_index_set_option: kw_hits_cap must be in 1 .. 2^31-1");
-        idx->kw_hits_cap = (uint32_t)value;
+        lanes([&](orr_index *x) { x->kw_hits_cap = (uint32_t)value; });
+        return ORR_OK;
+    }
+    if (strcmp(name, "max_lanes") == 0) {
+        if (value < 1 || value > 16) return fail(ORR_EINVAL, "orr_index_set_option: max_lanes must be in 1 .. 16");
+        if (idx->is_view) return fail(ORR_EINVAL, "orr_index_set_option: max_lanes applies to the owning index");
+        idx->max_lanes = std::max<int>((int)value, 1 + (int)idx->lanes.size());      // (lanes that exist stay)
         return ORR_OK;
     }
     if (strcmp(name, "shard_topk") == 0) {
         if (value < 0 || value > 1 << 30) return fail(ORR_EINVAL, "orr_index_set_option: shard_topk must be >= 0");
-        idx->opt_shard_topk = (int)value;
+        lanes([&](orr_index *x) { x->opt_shard_topk = (int)value; });
         return ORR_OK;
     }
     if (strcmp(name, "shard_pass") == 0) {
         if (value < 0 || value > 2) return fail(ORR_EINVAL, "orr_index_set_option: shard_pass takes 0, 1 or 2");
-        idx->opt_shard_pass = (int)value;
+        lanes([&](orr_index *x) { x->opt_shard_pass = (int)value; });
         return ORR_OK;
     }
     if (strcmp(name, "two_stage") == 0) {
@@ -1160,6 +1297,14 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
             HIP_TRY(hipSetDevice(idx->device));
             ORR_TRY(ensure_i8_shadow(idx));
             if (!idx->i8_ready) ORR_TRY(ensure_shadow(idx));
+        }
+        for (orr_index *l : idx->lanes) {               // the lanes borrow whatever shadow exists now
+            if (!l) continue;
+            l->opt_two_stage = (int)value;
+            l->emb_shadow.p = idx->emb_shadow.p; l->shadow_ready = idx->shadow_ready; l->shadow_failed = !idx->shadow_ready;
+            l->emb_i8.p = idx->emb_i8.p; l->i8_scale.p = idx->i8_scale.p; l->i8_rel_err.p = idx->i8_rel_err.p;
+            l->i8_rel_hat.p = idx->i8_rel_hat.p; l->i8_rowf.p = idx->i8_rowf.p;
+            l->i8_ready = idx->i8_ready; l->i8_failed = !idx->i8_ready;
         }
         return ORR_OK;
     }
@@ -1215,6 +1360,7 @@ int orr_index_view(orr_index *parent, orr_index **out)
 int orr_index_screen_dots(orr_index *idx, int32_t B, int32_t dim, const float *q, float *out)
 {
     if (!idx || !q || !out || B <= 0) return fail(ORR_EINVAL, "orr_index_screen_dots: bad argument");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
     if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_screen_dots: the index is not sealed");
     if (dim != idx->dim || dim <= 0 || dim % 64 != 0) return fail(ORR_EINVAL, "orr_index_screen_dots: dim must equal the index dimension and be a multiple of 64");
@@ -1243,6 +1389,7 @@ int orr_index_screen_i8_dots(orr_index *idx, int32_t B, int32_t dim, const float
                              int8_t *out_iq, int8_t *out_ie)
 {
     if (!idx || !q || B <= 0 || form < 0 || form > 2) return fail(ORR_EINVAL, "orr_index_screen_i8_dots: bad argument");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
     if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_screen_i8_dots: the index is not sealed");
     if (dim != idx->dim || dim <= 0 || dim % 128 != 0) return fail(ORR_EINVAL, "orr_index_screen_i8_dots: dim must equal the index dimension and be a multiple of 128");
@@ -1290,23 +1437,37 @@ int orr_index_screen_i8_dots(orr_index *idx, int32_t B, int32_t dim, const float
 int orr_index_set_profiling(orr_index *idx, int32_t enabled)
 {
     if (!idx) return fail(ORR_EINVAL, "null index");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
-    idx->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+    const int level = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+    idx->profiling = level;
     idx->stats.clear();
+    for (orr_index *l : idx->lanes) if (l) { l->profiling = level; l->stats.clear(); }
     return ORR_OK;
 }
 
 int orr_index_kernel_stats(orr_index *idx, orr_kernel_stat *out, int32_t cap)
 {
     if (!idx) return fail(ORR_EINVAL, "null index");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
-    const int32_t n = (int32_t)idx->stats.size();
+    std::vector<KernelStat> sum = idx->stats;           // every lane's launches, by kernel name
+    for (orr_index *l : idx->lanes) {
+        if (!l) continue;
+        for (const KernelStat &ks : l->stats) {
+            size_t i = 0;
+            while (i < sum.size() && sum[i].name != ks.name) ++i;
+            if (i == sum.size()) { sum.push_back(ks); continue; }
+            sum[i].launches += ks.launches; sum[i].total_ms += ks.total_ms; sum[i].algo_bytes += ks.algo_bytes;
+        }
+    }
+    const int32_t n = (int32_t)sum.size();
     for (int32_t i = 0; i < n && i < cap && out; ++i) {
         memset(&out[i], 0, sizeof(orr_kernel_stat));
-        strncpy(out[i].name, idx->stats[i].name.c_str(), sizeof(out[i].name) - 1);
-        out[i].launches = idx->stats[i].launches;
-        out[i].total_ms = idx->stats[i].total_ms;
-        out[i].algo_bytes = idx->stats[i].algo_bytes;
+        strncpy(out[i].name, sum[(size_t)i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = sum[(size_t)i].launches;
+        out[i].total_ms = sum[(size_t)i].total_ms;
+        out[i].algo_bytes = sum[(size_t)i].algo_bytes;
     }
     return n;
 }
@@ -2481,6 +2642,11 @@ int search_ids(orr_index *idx, const BatchArgs &orig, const std::vector<int32_t>
         while (cap < worst_unc_survivors + worst_unc_survivors / 8) cap *= 2;
         if (cap > idx->survivor_cap) idx->survivor_cap = cap;
         idx->sstats.buffer_growths += 1;
+        if (!idx->is_view || idx->internal_lane) {      // the other lanes of the handle start from the measured size as well
+            orr_index *own = const_cast<orr_index *>(owner_of(idx));
+            std::lock_guard<std::mutex> ll(own->lanes_mu);
+            own->survivor_cap_hint = std::max(own->survivor_cap_hint, cap);
+        }
     } else if (cur.used_fused && !cur.no_fuse) {
         next.no_fuse = true;                                   // a tie at the cut or an overflow too large to buffer: unfused pass
     } else if (cur.used_mfma) {
@@ -2502,11 +2668,29 @@ extern "C" {
 int orr_index_search_stats(orr_index *idx, orr_search_stats *out, int32_t reset)
 {
     if (!idx) return fail(ORR_EINVAL, "orr_index_search_stats: null index");
+    AllLanes all(idx);
     std::lock_guard<std::mutex> lock(idx->mu);
     idx->sstats.survivor_capacity = idx->survivor_cap;
     idx->sstats.vocab_tokens = idx->n_tokens;
-    if (out) *out = idx->sstats;
-    if (reset) { const int64_t cap = idx->sstats.survivor_capacity; idx->sstats = orr_search_stats{}; idx->sstats.survivor_capacity = cap; }
+    if (out) {
+        *out = idx->sstats;
+        for (orr_index *l : idx->lanes) {               // the counters of every lane of this handle
+            if (!l) continue;
+            const orr_search_stats &t = l->sstats;
+            out->searches += t.searches; out->queries += t.queries; out->passes += t.passes; out->requeried += t.requeried;
+            out->overflowed_queries += t.overflowed_queries; out->buffer_growths += t.buffer_growths;
+            out->exact_pass_queries += t.exact_pass_queries; out->survivors_total += t.survivors_total;
+            out->survivor_samples += t.survivor_samples; out->survivors_max = std::max(out->survivors_max, t.survivors_max);
+            out->survivor_capacity = std::max<int64_t>(out->survivor_capacity, l->survivor_cap);
+            out->kw_hits_total += t.kw_hits_total; out->kw_passes += t.kw_passes;
+            if (out->pass_mode == 0) out->pass_mode = t.pass_mode;
+        }
+    }
+    if (reset) {
+        auto clear = [](orr_index *x) { const int64_t cap = x->survivor_cap; x->sstats = orr_search_stats{}; x->sstats.survivor_capacity = cap; };
+        clear(idx);
+        for (orr_index *l : idx->lanes) if (l) clear(l);
+    }
     return ORR_OK;
 }
 
@@ -2569,6 +2753,9 @@ int orr_search_shard_ex(orr_index *idx, int32_t B, int32_t dim, const float *q, 
     if (kprime < 1) return fail(ORR_EINVAL, "orr_search_shard: kprime must be >= 1");
     if (!out) return fail(ORR_EINVAL, "orr_search_shard: out is NULL");
     if (pass < 0 || pass > 2 || topk < 0) return fail(ORR_EINVAL, "orr_search_shard_ex: pass takes 0, 1 or 2 and topk must be >= 0");
+    Lane ln;                                           // concurrent calls on one handle run on different lanes
+    ORR_TRY(ln.acquire(idx));
+    idx = ln.lane;
     std::lock_guard<std::mutex> lock(idx->mu);
     // the caller's escalation after a merge that could not certify every query (orr_merge_candidates)
     a.no_fuse = pass >= 1;
@@ -2645,6 +2832,9 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
     BatchArgs a{B, dim, q, terms_utf8, term_off, query_term_off, now_ticks, candidate_limit, topk};
     ORR_TRY(check_batch(idx, a, "orr_search_batch"));
     if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_search_batch: output buffers are required");
+    Lane ln;                                           // concurrent calls on one handle run on different lanes
+    ORR_TRY(ln.acquire(idx));
+    idx = ln.lane;
     std::lock_guard<std::mutex> lock(idx->mu);
     const int32_t take = std::max<int32_t>(1, topk);
     const int64_t n = participating_rows(idx, candidate_limit);
@@ -2676,23 +2866,86 @@ struct orr_cluster {
     std::vector<orr_index *> shards;
     int32_t dim = 0;
     bool sealed = false;
-    std::mutex mu;
+    std::shared_mutex mu;              // searches share it (they run side by side, each shard search on a lane of its shard); seal / destroy take it alone
+    std::mutex stats_mu;
     orr_search_stats sstats{};
 };
 
 namespace {
 
-// fn(i) for every shard, one thread each (the calling thread takes shard 0); returns the first failure
+// Persistent host threads for the shard halves of cluster searches: a search hands shards 1.. to the pool and runs shard 0
+// itself (round 2 started G - 1 threads per call).  The pool grows with demand (concurrent searches each need G - 1 workers)
+// up to a cap; its threads sleep between tasks and live as long as the process.
+class ShardPool {
+public:
+    static ShardPool &get() { static ShardPool *p = new ShardPool(); return *p; }
+    void submit(std::function<void()> task)
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        queue_.push_back(std::move(task));
+        if (idle_ == 0 && (int)threads_ < kMaxThreads && !forked_.load(std::memory_order_relaxed)) {
+            ++threads_;
+            std::thread([this] { loop(); }).detach();
+        }
+        l.unlock();
+        cv_.notify_one();
+    }
+    bool usable() const { return !forked_.load(std::memory_order_relaxed); }
+
+private:
+    static constexpr int kMaxThreads = 128;
+    ShardPool() { pthread_atfork(nullptr, nullptr, [] { forked_.store(true); }); }
+    void loop()
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        for (;;) {
+            ++idle_;
+            cv_.wait(l, [this] { return !queue_.empty(); });
+            --idle_;
+            std::function<void()> task = std::move(queue_.front());
+            queue_.pop_front();
+            l.unlock();
+            task();
+            l.lock();
+        }
+    }
+    static inline std::atomic<bool> forked_{false};
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> queue_;
+    int idle_ = 0;
+    unsigned threads_ = 0;
+};
+
+// fn(i) for every shard at once (the calling thread takes shard 0, pool threads the others); returns the first failure
 int for_each_shard(int32_t n, const std::function<int(int32_t)> &fn)
 {
     std::vector<int> rc((size_t)n, ORR_OK);
     std::vector<std::string> msg((size_t)n);
-    std::vector<std::thread> th;
-    for (int32_t i = 1; i < n; ++i)
-        th.emplace_back([&, i] { rc[(size_t)i] = fn(i); if (rc[(size_t)i] != ORR_OK) msg[(size_t)i] = g_last_error; });
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    int pending = 0;
+    const bool pooled = ShardPool::get().usable();
+    for (int32_t i = 1; i < n; ++i) {
+        auto task = [&, i] {
+            rc[(size_t)i] = fn(i);
+            if (rc[(size_t)i] != ORR_OK) msg[(size_t)i] = g_last_error;
+            std::lock_guard<std::mutex> l(done_mu);
+            if (--pending == 0) done_cv.notify_one();
+        };
+        {
+            std::lock_guard<std::mutex> l(done_mu);
+            ++pending;
+        }
+        if (pooled) ShardPool::get().submit(task);
+        else task();
+    }
     rc[0] = fn(0);
     if (rc[0] != ORR_OK) msg[0] = g_last_error;
-    for (auto &t : th) t.join();
+    {
+        std::unique_lock<std::mutex> l(done_mu);
+        done_cv.wait(l, [&] { return pending == 0; });
+    }
     for (int32_t i = 0; i < n; ++i)
         if (rc[(size_t)i] != ORR_OK) { g_last_error = msg[(size_t)i]; return rc[(size_t)i]; }     // (the detail was set on that shard's thread)
     return ORR_OK;
@@ -2727,8 +2980,14 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
     const size_t rec_per_shard = (size_t)nb * ((size_t)kprime + 1);
     std::vector<orr_candidate> all((size_t)G * rec_per_shard);
     std::vector<uint8_t> used_two_stage((size_t)G, 0), used_fused((size_t)G, 0), used_mfma((size_t)G, 0);
+    // every shard's half runs on a LANE of that shard (concurrent cluster searches take different lanes); the lanes stay held
+    // until this pass has looked at what the screen kept on them
+    std::vector<Lane> lanes((size_t)G);
+    std::vector<orr_index *> on((size_t)G, nullptr);
     ORR_TRY(for_each_shard(G, [&](int32_t g) -> int {
-        orr_index *sh = c->shards[(size_t)g];
+        ORR_TRY(lanes[(size_t)g].acquire(c->shards[(size_t)g]));
+        orr_index *sh = lanes[(size_t)g].lane;
+        on[(size_t)g] = sh;
         std::lock_guard<std::mutex> lock(sh->mu);
         BatchArgs mine = cur;
         const float *qh = nullptr;
@@ -2739,9 +2998,11 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
         used_two_stage[(size_t)g] = mine.used_two_stage; used_fused[(size_t)g] = mine.used_fused; used_mfma[(size_t)g] = mine.used_mfma;
         return ORR_OK;
     }));
+    std::unique_lock<std::mutex> stats_lock(c->stats_mu);
     c->sstats.passes += 1;
-    c->sstats.pass_mode = c->shards[0]->sstats.pass_mode;
+    c->sstats.pass_mode = on[0]->sstats.pass_mode;
     if (depth > 0) c->sstats.requeried += nb;
+    stats_lock.unlock();
     std::vector<uint8_t> cert((size_t)nb, 1);
     int32_t unc = 0;
     std::vector<int64_t> rows((size_t)nb * take);
@@ -2757,8 +3018,9 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
     }
     // survivors of the screening pass, per shard: statistics, and the buffer size a repeat needs
     bool any_fused = false, any_mfma = false, grow = false, only_overflow = unc > 0;
+    stats_lock.lock();
     for (int32_t g = 0; g < G; ++g) {
-        orr_index *sh = c->shards[(size_t)g];
+        orr_index *sh = on[(size_t)g];
         any_fused = any_fused || used_fused[(size_t)g];
         any_mfma = any_mfma || used_mfma[(size_t)g];
         if (!used_two_stage[(size_t)g] || (int32_t)sh->h_survivors.size() != nb) continue;
@@ -2775,35 +3037,45 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
             uint32_t cap = sh->pass_cap;
             while (cap < worst + worst / 8) cap *= 2;
             if (cap > sh->survivor_cap) { sh->survivor_cap = cap; grow = true; }
+            if (grow) {                                                     // (the repeat may run on another lane of this shard: the owner carries the size too)
+                orr_index *own = c->shards[(size_t)g];
+                std::lock_guard<std::mutex> ll(own->lanes_mu);
+                own->survivor_cap_hint = std::max(own->survivor_cap_hint, cap);
+            }
         } else if (worst > 0) {
             only_overflow = false;                                          // too many survivors to buffer: a more exact pass instead
         }
         c->sstats.survivor_capacity = std::max<int64_t>(c->sstats.survivor_capacity, sh->survivor_cap);
     }
+    stats_lock.unlock();
     if (unc == 0) return ORR_OK;
     // queries uncertified for a reason other than an overflowing buffer need a more exact pass whatever the buffers do
     if (grow) {
         for (int32_t g = 0; g < G && only_overflow; ++g) {
-            orr_index *sh = c->shards[(size_t)g];
+            orr_index *sh = on[(size_t)g];
             if (!used_two_stage[(size_t)g] || (int32_t)sh->h_survivors.size() != nb) { only_overflow = false; break; }
         }
         if (only_overflow)
             for (int32_t i = 0; i < nb && only_overflow; ++i) {
                 if (cert[(size_t)i]) continue;
                 bool over = false;
-                for (int32_t g = 0; g < G; ++g) over = over || c->shards[(size_t)g]->h_survivors[(size_t)i] > c->shards[(size_t)g]->pass_cap;
+                for (int32_t g = 0; g < G; ++g) over = over || on[(size_t)g]->h_survivors[(size_t)i] > on[(size_t)g]->pass_cap;
                 only_overflow = over;
             }
     }
+    // (a grown buffer size belongs to the lane that measured it; the shard's other lanes learn it when they overflow themselves)
+    lanes.clear();                                      // the repeat below takes lanes of its own
     std::vector<int32_t> again;
     for (int32_t i = 0; i < nb; ++i) if (!cert[(size_t)i]) again.push_back(ids[(size_t)i]);
     BatchArgs next = orig;
     if (grow && only_overflow) {
+        std::lock_guard<std::mutex> l(c->stats_mu);
         c->sstats.buffer_growths += 1;                                       // the same pass again with buffers sized from the measured counts
     } else if (any_fused && !orig.no_fuse) {
         next.no_fuse = true;
     } else if (any_mfma && !orig.force_exact) {
         next.force_exact = true;
+        std::lock_guard<std::mutex> l(c->stats_mu);
         c->sstats.exact_pass_queries += (int64_t)again.size();
     } else if (kprime >= n_total) {
         return ORR_OK;
@@ -2862,7 +3134,7 @@ int64_t orr_cluster_rows(const orr_cluster *c)
 int orr_cluster_seal(orr_cluster *c)
 {
     if (!c) return fail(ORR_EINVAL, "orr_cluster_seal: null cluster");
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::unique_lock<std::shared_mutex> lock(c->mu);
     ORR_TRY(for_each_shard((int32_t)c->shards.size(), [&](int32_t g) { return orr_index_seal(c->shards[(size_t)g]); }));
     int64_t base = 0, dead = 0;
     const orr_index *prev = nullptr;
@@ -2890,15 +3162,21 @@ int orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, const float
     ORR_TRY(check_batch(c->shards[0], a, "orr_cluster_search_batch"));
     if (!out_rows || !out_scores) return fail(ORR_EINVAL, "orr_cluster_search_batch: output buffers are required");
     if (dim > 0 && is_device_pointer(q_host)) return fail(ORR_EINVAL, "orr_cluster_search_batch: the query vectors must be in host memory (every shard's device reads them)");
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::shared_lock<std::shared_mutex> lock(c->mu);   // searches run side by side; seal and destroy are exclusive
     if (!c->sealed) return fail(ORR_ESTATE, "orr_cluster_search_batch: the cluster is not sealed");
     {   // rows deleted from a shard since the seal (orr_index_delete_rows on orr_cluster_shard(i)) shift the candidate_limit prefix
-        // of every shard behind it: the dead-row prefix sums are taken afresh for every search
+        // of every shard behind it: when the dead-row prefix sums changed they are set again (an option of the shard: every lane
+        // of it is idle while it changes)
         int64_t dead = 0;
         for (orr_index *sh : c->shards) {
-            std::lock_guard<std::mutex> sl(sh->mu);
-            sh->dead_before = dead;
-            dead += (int64_t)sh->dead.size();
+            int64_t have, mine;
+            {
+                std::lock_guard<std::mutex> sl(sh->lanes_mu);
+                have = sh->dead_before_pub;
+                mine = sh->dead_count_pub;
+            }
+            if (have != dead) ORR_TRY(orr_index_set_option(sh, "dead_rows_before", dead));
+            dead += mine;
         }
     }
     const int32_t take = std::max<int32_t>(1, topk);
@@ -2907,8 +3185,11 @@ int orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, const float
     // k' per shard as orr_search_batch picks it for one shard: any shard may hold the whole top-k
     int64_t kprime = std::min<int64_t>(std::max<int64_t>(1, n_total), std::max<int64_t>((int64_t)take + 22, 32));
     if (kprime > orr::kSelWidth && take + 8 <= orr::kSelWidth) kprime = orr::kSelWidth;
-    c->sstats.searches += 1;
-    c->sstats.queries += B;
+    {
+        std::lock_guard<std::mutex> l(c->stats_mu);
+        c->sstats.searches += 1;
+        c->sstats.queries += B;
+    }
     for (int64_t i = 0; i < (int64_t)B * take; ++i) { out_rows[i] = -1; out_scores[i] = 0.0; }
     std::vector<int32_t> all((size_t)B);
     std::iota(all.begin(), all.end(), 0);
@@ -2918,7 +3199,7 @@ int orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, const float
 int orr_cluster_search_stats(orr_cluster *c, orr_search_stats *out, int32_t reset)
 {
     if (!c) return fail(ORR_EINVAL, "orr_cluster_search_stats: null cluster");
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::mutex> lock(c->stats_mu);
     if (out) *out = c->sstats;
     if (reset) c->sstats = orr_search_stats{};
     return ORR_OK;

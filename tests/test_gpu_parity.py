@@ -933,3 +933,51 @@ def test_four_wave_screening_kernel_variants_match_oracle():
     rows1, scores1, counts1 = idx.search(qs[:130], terms[:130], NOW, 10, candidate_limit=n)
     assert np.array_equal(counts0, counts1) and np.array_equal(rows0, rows1) and np.array_equal(scores0, scores1)
     idx.close()
+
+
+def test_shard_records_are_complete_when_orr_search_shard_returns():
+    """The stream contract the record exchange leans on (sharded.py, include/omnirecall_hip.h conventions): a DEVICE-resident
+    `out` of orr_search_shard(_ex) is complete when the call returns, although the library wrote it on its own non-blocking
+    stream.  Here the buffer is read back on a fresh stream of the caller's immediately after the call (what a collective
+    on the process group's stream does) and must equal the records of the same search written to host memory."""
+    import importlib
+    import torch
+    P = pkg()
+    sh = importlib.import_module("omni_recall_rag_amd.sharded")
+    rng = np.random.default_rng(99)
+    n, dim = 300_000, 128
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm"])
+    contents = [" ".join(w).encode() for w in words[rng.integers(0, len(words), (n, 3))]]
+    idx = P.RecallIndex(dim=dim, row_base=1_000_000)
+    for r0 in range(0, n, 100_000):
+        idx.append(emb[r0:r0 + 100_000], created[r0:r0 + 100_000], contents[r0:r0 + 100_000])
+    idx.seal()
+    front = sh.ShardedRecallSearch(idx, dim, "cuda:0")          # no process group: one rank, the same code path minus the collective
+    snaps = []
+    side = torch.cuda.Stream()
+
+    def snapshot(mine, nb, kprime):
+        with torch.cuda.stream(side):                           # NOT the library's stream, and nothing synchronises with it
+            host = torch.empty(mine.numel(), dtype=torch.uint8, pin_memory=True)
+            host.copy_(mine, non_blocking=True)
+        side.synchronize()
+        snaps.append((host.numpy().copy(), nb, kprime))
+
+    front._shard_search_done = snapshot
+    B, kprime = 48, 32
+    q = torch.from_numpy(rng.standard_normal((B, dim)).astype(np.float32)).cuda()
+    terms = [P.text.query_terms(QUERY_TEXTS[b % len(QUERY_TEXTS)]) for b in range(B)]
+    for trial in range(3):
+        snaps.clear()
+        rows, scores, counts = front.search_from(0, q, terms, NOW, 10, 1_000_000 + n, kprime=kprime)
+        assert snaps and snaps[0][1] == B
+        want = idx.search_shard(q, terms, NOW, kprime, 1_000_000 + n, topk=10, shard_pass=0)       # the same search into host memory
+        got = snaps[0][0].view(P.CAND_DTYPE).reshape(B, kprime + 1)
+        for f in ("order_key", "row_id", "matches", "flags", "created_ticks"):
+            assert np.array_equal(got[f], want[f]), (trial, f)
+        assert np.array_equal(got["dot"], want["dot"]) and np.array_equal(got["norm_b"], want["norm_b"])
+        r2, s2, c2 = idx.search(q, terms, NOW, 10, candidate_limit=1_000_000 + n)
+        assert np.array_equal(rows, r2) and np.array_equal(scores, s2) and np.array_equal(counts, c2)
+    idx.close()

@@ -102,23 +102,39 @@ def c_string(lines):
     return " \\\n    ".join('"%s\\n\\t"' % l for l in lines)
 
 
+def render():
+    out = []
+    out.append("// GENERATED by tools/gen_tile16_asm.py -- do not edit; see that script for the schedule and the register plan.\n")
+    out.append("#define ORR_T16_ZERO \\\n    " + c_string(["v_accvgpr_write_b32 a%d, 0" % n for n in range(256)]) + "\n")
+    for name, req, nt in (("REQ", True, False), ("REQ_NT", True, True), ("NOREQ", False, False)):
+        out.append("#define ORR_T16_KTILE_%s \\\n    %s\n" % (name, c_string(k_tile(req, nt))))
+        out.append("#define ORR_T16_KTILE_FIRST_%s \\\n    %s\n" % (name, c_string(k_tile(req, nt, True))))
+    # the same K-tile in two statements (up to and including the barrier / the rest): the epilogue's loads are requested
+    # between them -- behind the K-tile's counted wait, which would otherwise wait for them as well
+    lines = k_tile(False, False)
+    cut = lines.index("s_barrier") + 1
+    out.append("#define ORR_T16_KTILE_NOREQ_H1 \\\n    %s\n" % c_string(lines[:cut]))
+    out.append("#define ORR_T16_KTILE_NOREQ_H2 \\\n    %s\n" % c_string(lines[cut:]))
+    out.append("#define ORR_T16_ACC_CLOBBERS " + ", ".join('"a%d"' % n for n in range(256)) + "\n")
+    return "".join(out)
+
+
 def main():
+    import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "omni-recall-rag_amd", "csrc", "orr_screen_tile16_asm.inc")
+    path = os.path.normpath(os.path.join(here, "..", "omni-recall-rag_amd", "csrc", "orr_screen_tile16_asm.inc"))
+    text = render()
+    if "--check" in sys.argv[1:]:
+        # the Makefile's guard: the committed text must be what this script makes (the script is the source of the K-tile)
+        with open(path) as f:
+            have = f.read()
+        if have != text:
+            sys.stderr.write("%s is not what tools/gen_tile16_asm.py generates: run the script and commit its output\n" % path)
+            raise SystemExit(1)
+        return
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_tile16_asm.py -- do not edit; see that script for the schedule and the register plan.\n")
-        f.write("#define ORR_T16_ZERO \\\n    " + c_string(["v_accvgpr_write_b32 a%d, 0" % n for n in range(256)]) + "\n")
-        for name, req, nt in (("REQ", True, False), ("REQ_NT", True, True), ("NOREQ", False, False)):
-            f.write("#define ORR_T16_KTILE_%s \\\n    %s\n" % (name, c_string(k_tile(req, nt))))
-            f.write("#define ORR_T16_KTILE_FIRST_%s \\\n    %s\n" % (name, c_string(k_tile(req, nt, True))))
-        # the same K-tile in two statements (up to and including the barrier / the rest): the epilogue's loads are requested
-        # between them -- behind the K-tile's counted wait, which would otherwise wait for them as well
-        lines = k_tile(False, False)
-        cut = lines.index("s_barrier") + 1
-        f.write("#define ORR_T16_KTILE_NOREQ_H1 \\\n    %s\n" % c_string(lines[:cut]))
-        f.write("#define ORR_T16_KTILE_NOREQ_H2 \\\n    %s\n" % c_string(lines[cut:]))
-        f.write("#define ORR_T16_ACC_CLOBBERS " + ", ".join('"a%d"' % n for n in range(256)) + "\n")
-    print("wrote", os.path.normpath(path))
+        f.write(text)
+    print("wrote", path)
 
 
 if __name__ == "__main__":
