@@ -265,6 +265,19 @@ int orr_index_view(orr_index *parent, orr_index **view);
 int     orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int64_t *out_deleted);
 int64_t orr_index_live_rows(const orr_index *idx);
 
+/* ---- compaction ------------------------------------------------------------------
+ * Rebuilds a sealed shard IN PLACE without its deleted rows -- the other half of "replace the chunk list"
+ * (InMemoryIngestionStore.cs:17-25, 50-55), where the reference simply drops the old list: embeddings move up
+ * chunk by chunk through a 256 MiB bounce buffer (no second copy of the shard), norms / timestamps / ids are
+ * gathered, every posting list of the token index loses the deleted positions and is renumbered, the shadows are
+ * dropped and rebuilt at the next search that wants them.  Row ids are kept; positions (order keys) close up, so a
+ * shard BEHIND this one in a global order moves up by *out_removed (may be NULL) rows: give it its new row_base
+ * (orr_index_set_row_base) and "dead_rows_before" -- orr_cluster_compact does both for a cluster.  Lifts the
+ * quarter-of-the-shard limit of orr_index_delete_rows.  Exclusive like delete; ORR_ESTATE while views made with
+ * orr_index_view are alive (they borrow the arrays that move).  A failure half way (ORR_EDEVICE / ORR_ENOMEM)
+ * leaves the shard unusable: rebuild it. */
+int orr_index_compact(orr_index *idx, int64_t *out_removed);
+
 /* ---- tuning knobs ----------------------------------------------------------
  * Integer options of one index; unknown names are ORR_EINVAL.
  *   "dead_rows_before"  deleted rows in the shards in front of this one (default 0), see above.
@@ -351,6 +364,8 @@ int        orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, cons
                                     int64_t candidate_limit, int64_t *out_rows, double *out_scores,
                                     int32_t *out_counts);
 int        orr_cluster_search_stats(orr_cluster *c, orr_search_stats *out, int32_t reset);
+/* orr_index_compact on every shard (concurrently), then the shards are placed in the global order again. */
+int        orr_cluster_compact(orr_cluster *c, int64_t *out_removed);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,8 @@ void          orrh_service_destroy(orrh_service *svc);
  * a shard deleted trigger a full rebuild.  Counters for tests/metrics: */
 void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebuilds, int64_t *delta_builds);
 int64_t orrh_service_tombstoned_rows(orrh_service *svc);    /* rows dropped in place so far */
+int64_t orrh_service_compactions(orrh_service *svc);        /* shards compacted in place (orr_index_compact) instead of rebuilt, when more than a
+                                                               quarter of a shard's rows had been dropped */
 /* SearchAsync(query, topK) with the query embedding supplied by the caller (the
  * IEmbeddingClient result; qdim 0 = empty vector) and a frozen clock.  *out_json is
  * malloc'd; release it with orrh_free.  A blank query is ORR_EINVAL "Query is required." */

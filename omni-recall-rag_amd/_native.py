@@ -94,6 +94,10 @@ hip.orr_index_set_option.restype = C.c_int
 hip.orr_index_set_option.argtypes = [_vp, C.c_char_p, _i64]
 hip.orr_index_delete_rows.restype = C.c_int
 hip.orr_index_delete_rows.argtypes = [_vp, _i64, _vp, _vp]
+hip.orr_index_compact.restype = C.c_int
+hip.orr_index_compact.argtypes = [_vp, _vp]
+hip.orr_cluster_compact.restype = C.c_int
+hip.orr_cluster_compact.argtypes = [_vp, _vp]
 hip.orr_index_live_rows.restype = _i64
 hip.orr_index_live_rows.argtypes = [_vp]
 hip.orr_index_view.restype = C.c_int
@@ -162,6 +166,8 @@ host.orrh_service_stats.restype = None
 host.orrh_service_stats.argtypes = [_vp, _vp, _vp, _vp]
 host.orrh_service_tombstoned_rows.restype = _i64
 host.orrh_service_tombstoned_rows.argtypes = [_vp]
+host.orrh_service_compactions.restype = _i64
+host.orrh_service_compactions.argtypes = [_vp]
 host.orrh_service_destroy.restype = None
 host.orrh_service_destroy.argtypes = [_vp]
 host.orrh_service_search_json.restype = C.c_int
@@ -192,7 +198,7 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_index_append", "orr_index_seal", "orr_index_rows", "orr_index_dim", "orr_search_batch",
     "orr_search_shard", "orr_search_shard_ex", "orr_merge_candidates", "orr_merge_candidates_ex", "orr_index_set_profiling", "orr_index_kernel_stats",
     "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_screen_i8_dots", "orr_index_view",
-    "orr_index_delete_rows", "orr_index_live_rows", "orr_index_search_stats",
+    "orr_index_delete_rows", "orr_index_live_rows", "orr_index_compact", "orr_cluster_compact", "orr_index_search_stats",
     "orr_cluster_create", "orr_cluster_destroy", "orr_cluster_shards", "orr_cluster_shard", "orr_cluster_seal", "orr_cluster_rows",
     "orr_cluster_search_batch", "orr_cluster_search_stats",
 ]
@@ -200,7 +206,7 @@ EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_te
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_store_import_cosmos_json", "orrh_store_export_cosmos_json", "orrh_service_create", "orrh_service_destroy",
-                         "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
+                         "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_service_compactions", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
                          "orrh_batcher_search", "orrh_batcher_search_at", "orrh_batcher_stats"]
 
 

@@ -93,6 +93,7 @@ struct Shard {                       // one sealed orr_index and the chunks behi
     std::map<std::string, uint64_t> doc_stamps;      // documents with live rows here -> version of their chunk list
     std::vector<char> dead;          // rows deleted in place (orr_index_delete_rows), by position in `chunks`
     int64_t n_dead = 0;
+    int64_t n_dead_compacted = 0;    // of those, rows that have left the device arrays (orr_index_compact)
 };
 
 struct orrh_service {
@@ -104,7 +105,7 @@ struct orrh_service {
     int32_t dim = 0;
     uint64_t built_version = ~0ull;
     int64_t next_id = 0;
-    int64_t full_rebuilds = 0, delta_builds = 0, tombstoned_rows = 0;
+    int64_t full_rebuilds = 0, delta_builds = 0, tombstoned_rows = 0, compactions = 0;
 };
 
 namespace {
@@ -197,8 +198,8 @@ void assign_row_bases(orrh_service *svc)
     for (auto &sh : svc->shards) {                    // newest shard first
         orr_index_set_row_base(sh.index, base);
         orr_index_set_option(sh.index, "dead_rows_before", dead);      // candidate_limit counts live rows
-        base += (int64_t)sh.chunks.size();
-        dead += sh.n_dead;
+        base += orr_index_rows(sh.index);                              // (rows on the device: compaction removed some of the mirror's)
+        dead += orr_index_rows(sh.index) - orr_index_live_rows(sh.index);
     }
 }
 
@@ -231,8 +232,18 @@ int ensure_index(orrh_service *svc)
                     marked.push_back(p);
                 }
             int64_t done = 0;
-            const int r = orr_index_delete_rows(sh.index, (int64_t)ids.size(), ids.data(), &done);
-            if (r == ORR_ESTATE) changed = true;              // too much of the shard is gone: rebuild below
+            int r = orr_index_delete_rows(sh.index, (int64_t)ids.size(), ids.data(), &done);
+            if (r == ORR_ESTATE) {
+                // more than a quarter of the shard would be tombstones: compact it in place (the rows deleted so far leave the
+                // device arrays; ids are kept, so the mirror's id -> chunk map stands) and delete again
+                int64_t removed = 0;
+                if (orr_index_compact(sh.index, &removed) == ORR_OK) {
+                    svc->compactions++;
+                    sh.n_dead_compacted += removed;
+                    r = orr_index_delete_rows(sh.index, (int64_t)ids.size(), ids.data(), &done);
+                }
+            }
+            if (r == ORR_ESTATE) changed = true;              // still too much of the shard is gone: rebuild below
             else if (r != ORR_OK) return fail(r, orr_last_error());     // (nothing was marked: the mirror still matches the index)
             else {
                 for (size_t p : marked) sh.dead[p] = 1;       // only once the index has dropped them
@@ -418,6 +429,13 @@ void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebu
     if (n_shards) *n_shards = (int32_t)svc->shards.size();
     if (full_rebuilds) *full_rebuilds = svc->full_rebuilds;
     if (delta_builds) *delta_builds = svc->delta_builds;
+}
+
+int64_t orrh_service_compactions(orrh_service *svc)
+{
+    if (!svc) return 0;
+    std::lock_guard<std::mutex> l(svc->mu);
+    return svc->compactions;
 }
 
 int64_t orrh_service_tombstoned_rows(orrh_service *svc)

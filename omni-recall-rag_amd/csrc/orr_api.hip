@@ -210,6 +210,7 @@ struct orr_index {
     bool internal_lane = false;            // this view belongs to its parent's lane pool (not handed to the caller)
     int64_t dead_before_pub = 0, dead_count_pub = 0;   // (under lanes_mu) copies of dead_before / dead.size() a cluster reads without waiting for searches
     uint32_t survivor_cap_hint = 0;        // (under lanes_mu) a lane measured that the survivors' buffers must be at least this large
+    std::atomic<int> user_views{0};        // views handed to the caller (orr_index_view) that are still alive: they pin the shard's layout
 
     // profiling
     int profiling = 0;                     // 0 off, 1 every kernel, 2 only the pass over all rows (the kernel a roofline is quoted on)
@@ -218,7 +219,7 @@ struct orr_index {
     std::vector<hipEvent_t> event_pool;
 };
 
-extern "C" int orr_index_view(orr_index *parent, orr_index **view);
+static int make_view(orr_index *parent, orr_index **out, bool internal);
 
 namespace {
 
@@ -256,10 +257,9 @@ struct Lane {
                 idx->lane_busy.push_back(1);
                 lk.unlock();
                 orr_index *v = nullptr;
-                const int r = orr_index_view(idx, &v);             // (waits for the search that holds the index's own lane)
+                const int r = make_view(idx, &v, true);            // (waits for the search that holds the index's own lane)
                 lk.lock();
                 if (r == ORR_OK) {
-                    v->internal_lane = true;
                     idx->lanes[i] = v; slot = (int)i + 1; lane = v;
                     return ORR_OK;
                 }
@@ -673,6 +673,7 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
 void orr_index_destroy(orr_index *idx)
 {
     if (!idx) return;
+    if (idx->is_view && !idx->internal_lane && idx->parent) const_cast<orr_index *>(idx->parent)->user_views.fetch_sub(1);
     if (!idx->is_view) {                               // the internal lanes go first (they borrow the corpus)
         std::vector<orr_index *> lanes;
         {
@@ -1256,6 +1257,129 @@ int orr_index_delete_rows(orr_index *idx, int64_t n, const int64_t *row_ids, int
     return ORR_OK;
 }
 
+int orr_index_compact(orr_index *idx, int64_t *out_removed)
+{
+    if (out_removed) *out_removed = 0;
+    if (!idx) return fail(ORR_EINVAL, "orr_index_compact: null index");
+    if (idx->is_view) return fail(ORR_EINVAL, "orr_index_compact: compact the owning index, not a view");
+    std::vector<orr_index *> old_lanes;
+    AllLanes all(idx);                                 // no search in flight while rows move
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (!idx->sealed) return fail(ORR_ESTATE, "orr_index_compact: the index is not sealed");
+    if (idx->user_views.load() > 0)
+        return fail(ORR_ESTATE, "orr_index_compact: %d view(s) of this index are alive (orr_index_view): destroy them first", idx->user_views.load());
+    if (idx->dead.empty()) return ORR_OK;
+    HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    const int64_t n = idx->n_rows, n_dead = (int64_t)idx->dead.size(), n_new = n - n_dead;
+    // live positions, ascending (= the new candidate order), and how far each old position moves up
+    std::vector<int64_t> live((size_t)n_new);
+    std::vector<uint32_t> shift((size_t)n + 1);
+    {
+        size_t d = 0, w = 0;
+        for (int64_t p = 0; p < n; ++p) {
+            shift[(size_t)p] = (uint32_t)d;
+            if (d < idx->dead.size() && idx->dead[d] == p) { ++d; continue; }
+            live[w++] = p;
+        }
+        shift[(size_t)n] = (uint32_t)d;
+    }
+    DevBuf d_live;
+    ORR_TRY(d_live.reserve(sizeof(int64_t) * (size_t)std::max<int64_t>(n_new, 1)));
+    int r = ORR_OK;
+    auto body = [&]() -> int {
+        if (n_new > 0) HIP_TRY(hipMemcpy(d_live.p, live.data(), sizeof(int64_t) * (size_t)n_new, hipMemcpyHostToDevice));
+        // ---- embeddings: IN PLACE, chunk by chunk through a bounce buffer (a second copy of a 150 GB shard does not fit).  Rows only
+        // move towards lower positions, and chunks go in ascending order, so a chunk's destination never reaches rows a later chunk
+        // still has to read.
+        if (idx->dim > 0 && n_new > 0) {
+            const int64_t first_moved = idx->dead.front();                  // rows in front of the first deleted one stay where they are
+            const int64_t chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)sizeof(float) * idx->dim));
+            DevBuf bounce;
+            ORR_TRY(bounce.reserve(sizeof(float) * (size_t)chunk * idx->dim));
+            int64_t w0 = first_moved;                                       // live[w0] is the first row that moves (w0 rows in front of it are live)
+            w0 = (int64_t)(std::lower_bound(live.begin(), live.end(), first_moved) - live.begin());
+            for (int64_t w = w0; w < n_new; w += chunk) {
+                const int64_t m = std::min<int64_t>(chunk, n_new - w);
+                const hipError_t e1 = orr::launch_gather_rows_f32(idx->d_emb, bounce.as<float>(), d_live.as<int64_t>() + w, m, idx->dim, s);
+                if (e1 != hipSuccess) { bounce.release(); return fail(ORR_EDEVICE, "orr_index_compact: gather failed: %s", hipGetErrorString(e1)); }
+                const hipError_t e2 = hipMemcpyAsync(idx->d_emb + (size_t)w * idx->dim, bounce.p, sizeof(float) * (size_t)m * idx->dim, hipMemcpyDeviceToDevice, s);
+                if (e2 != hipSuccess) { bounce.release(); return fail(ORR_EDEVICE, "orr_index_compact: copy failed: %s", hipGetErrorString(e2)); }
+            }
+            const hipError_t e3 = hipStreamSynchronize(s);
+            bounce.release();
+            if (e3 != hipSuccess) return fail(ORR_EDEVICE, "orr_index_compact: %s", hipGetErrorString(e3));
+        }
+        // ---- per-row scalars: gathered into new arrays (8 bytes per row each)
+        int64_t *nc = nullptr, *nr = nullptr, *nn = nullptr;
+        ORR_TRY(dev_alloc(&nc, (size_t)idx->cap_rows));
+        ORR_TRY(dev_alloc(&nr, (size_t)idx->cap_rows));
+        ORR_TRY(dev_alloc(&nn, (size_t)std::max<int64_t>(n, 1)));
+        if (n_new > 0) {
+            HIP_TRY(orr::launch_gather_i64(idx->d_created, nc, d_live.as<int64_t>(), n_new, s));
+            HIP_TRY(orr::launch_gather_i64(idx->d_row_ids, nr, d_live.as<int64_t>(), n_new, s));
+            HIP_TRY(orr::launch_gather_i64(reinterpret_cast<const int64_t *>(idx->d_norm_b), nn, d_live.as<int64_t>(), n_new, s));   // (the norms as bit patterns)
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(idx->d_created); idx->d_created = nc;
+        (void)hipFree(idx->d_row_ids); idx->d_row_ids = nr;
+        (void)hipFree(idx->d_norm_b); idx->d_norm_b = reinterpret_cast<double *>(nn);
+        // ---- token index: every posting list loses the deleted positions and is renumbered (on the host: one pass over the postings)
+        if (idx->n_postings > 0) {
+            const size_t V = (size_t)idx->n_tokens;
+            std::vector<uint64_t> off(V + 1), noff(V + 1);
+            std::vector<uint32_t> rows((size_t)idx->n_postings);
+            HIP_TRY(hipMemcpy(off.data(), idx->d_post_off, sizeof(uint64_t) * (V + 1), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rows.data(), idx->d_post_rows, sizeof(uint32_t) * rows.size(), hipMemcpyDeviceToHost));
+            size_t w = 0;
+            for (size_t t = 0; t < V; ++t) {
+                noff[t] = w;
+                for (uint64_t i = off[t]; i < off[t + 1]; ++i) {
+                    const uint32_t p = rows[(size_t)i];
+                    if (shift[(size_t)p + 1] != shift[(size_t)p]) continue;       // a deleted row
+                    rows[w++] = p - shift[(size_t)p];
+                }
+            }
+            noff[V] = w;
+            HIP_TRY(hipMemcpy(idx->d_post_off, noff.data(), sizeof(uint64_t) * (V + 1), hipMemcpyHostToDevice));
+            if (w) HIP_TRY(hipMemcpy(idx->d_post_rows, rows.data(), sizeof(uint32_t) * w, hipMemcpyHostToDevice));
+            idx->n_postings = w;
+        }
+        return ORR_OK;
+    };
+    r = body();
+    d_live.release();
+    if (r != ORR_OK) return r;                         // (a failure half way leaves the shard unusable: the caller rebuilds it)
+    // ---- host mirrors
+    {
+        std::vector<int64_t> hc((size_t)n_new);
+        std::vector<uint32_t> hl((size_t)n_new);
+        for (int64_t w = 0; w < n_new; ++w) { hc[(size_t)w] = idx->h_created[(size_t)live[(size_t)w]]; hl[(size_t)w] = idx->h_clen[(size_t)live[(size_t)w]]; }
+        idx->h_created.swap(hc);
+        idx->h_clen.swap(hl);
+        idx->h_cprefix.assign((size_t)n_new + 1, 0);
+        for (int64_t w = 0; w < n_new; ++w) idx->h_cprefix[(size_t)w + 1] = idx->h_cprefix[(size_t)w] + idx->h_clen[(size_t)w];
+    }
+    idx->n_rows = n_new;
+    idx->dead.clear();
+    idx->d_dead.release();
+    idx->id_index.clear();
+    // derived copies are rebuilt at the next search that wants them; the lanes' borrowed pointers die with the lanes
+    idx->emb_shadow.release(); idx->shadow_ready = false; idx->shadow_failed = false;
+    idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
+    idx->i8_ready = false; idx->i8_failed = false;
+    idx->bitmaps_clean = 0; idx->bitmaps_clean_of = nullptr;
+    {
+        std::lock_guard<std::mutex> ll(idx->lanes_mu);
+        old_lanes.swap(idx->lanes);
+        idx->lane_busy.clear();
+        idx->dead_count_pub = 0;
+    }
+    for (orr_index *l : old_lanes) if (l) orr_index_destroy(l);
+    if (out_removed) *out_removed = n_dead;
+    return ORR_OK;
+}
+
 int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
 {
     if (!idx || !name) return fail(ORR_EINVAL, "orr_index_set_option: null argument");
@@ -1311,7 +1435,11 @@ int orr_index_set_option(orr_index *idx, const char *name, int64_t value)
     return fail(ORR_EINVAL, "orr_index_set_option: unknown option %s", name);
 }
 
-int orr_index_view(orr_index *parent, orr_index **out)
+static int make_view(orr_index *parent, orr_index **out, bool internal);
+
+int orr_index_view(orr_index *parent, orr_index **out) { return make_view(parent, out, false); }
+
+static int make_view(orr_index *parent, orr_index **out, bool internal)
 {
     if (!parent || !out) return fail(ORR_EINVAL, "orr_index_view: null argument");
     *out = nullptr;
@@ -1350,9 +1478,12 @@ int orr_index_view(orr_index *parent, orr_index **out)
         hipEventCreateWithFlags(&v->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
         !create_range_events(v->ev_range) ||
         hipEventCreateWithFlags(&v->ev_q, hipEventDisableTiming) != hipSuccess) {
+        v->internal_lane = true;                       // (not counted yet: the destroy must not count it down)
         orr_index_destroy(v);
         return fail(ORR_EDEVICE, "cannot create streams on device %d", parent->device);
     }
+    v->internal_lane = internal;
+    if (!internal) parent->user_views.fetch_add(1);
     *out = v;
     return ORR_OK;
 }
@@ -3150,6 +3281,32 @@ int orr_cluster_seal(orr_cluster *c)
         if (sh->n_rows > 0) prev = sh;
     }
     c->sealed = true;
+    return ORR_OK;
+}
+
+// places the shards in the global candidate order: row_base and the deleted rows in front of each
+static int place_shards(orr_cluster *c)
+{
+    int64_t base = 0, dead = 0;
+    for (orr_index *sh : c->shards) {
+        ORR_TRY(orr_index_set_row_base(sh, base));
+        ORR_TRY(orr_index_set_option(sh, "dead_rows_before", dead));
+        base += sh->n_rows;
+        dead += (int64_t)sh->dead.size();
+    }
+    return ORR_OK;
+}
+
+int orr_cluster_compact(orr_cluster *c, int64_t *out_removed)
+{
+    if (out_removed) *out_removed = 0;
+    if (!c) return fail(ORR_EINVAL, "orr_cluster_compact: null cluster");
+    std::unique_lock<std::shared_mutex> lock(c->mu);   // no search in flight on the cluster
+    if (!c->sealed) return fail(ORR_ESTATE, "orr_cluster_compact: the cluster is not sealed");
+    std::vector<int64_t> removed(c->shards.size(), 0);
+    ORR_TRY(for_each_shard((int32_t)c->shards.size(), [&](int32_t g) { return orr_index_compact(c->shards[(size_t)g], &removed[(size_t)g]); }));
+    ORR_TRY(place_shards(c));                          // the shards behind a compacted one move up in the global order
+    if (out_removed) for (int64_t r : removed) *out_removed += r;
     return ORR_OK;
 }
 

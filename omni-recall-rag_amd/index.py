@@ -134,6 +134,12 @@ class RecallIndex:
     def live_rows(self) -> int:
         return int(N.hip.orr_index_live_rows(self._h))
 
+    def compact(self) -> int:
+        """orr_index_compact: the shard rebuilt in place without its deleted rows.  Returns the rows removed."""
+        done = C.c_int64(0)
+        N.check(N.hip.orr_index_compact(self._h, C.cast(C.byref(done), C.c_void_p)))
+        return int(done.value)
+
     def save(self, path: str) -> None:
         """orr_index_save: the sealed shard as one binary file."""
         N.check(N.hip.orr_index_save(self._h, path.encode()))
@@ -317,6 +323,12 @@ class RecallCluster:
         N.check(N.hip.orr_cluster_search_batch(self._h, B, dim, _ptr(q), _ptr(pool), _ptr(toff), _ptr(qoff), now_ticks, int(topk),
                                                int(candidate_limit), _ptr(rows), _ptr(scores), _ptr(counts)))
         return rows, scores, counts
+
+    def compact(self) -> int:
+        """orr_cluster_compact: every shard without its deleted rows, placed in the global order again."""
+        done = C.c_int64(0)
+        N.check(N.hip.orr_cluster_compact(self._h, C.cast(C.byref(done), C.c_void_p)))
+        return int(done.value)
 
     def search_stats(self, reset: bool = False) -> dict:
         st = N.OrrSearchStats()

@@ -129,7 +129,8 @@ class RecallSearchService:
         N.host.orrh_service_stats(self._h, C.cast(C.byref(n), C.c_void_p), C.cast(C.byref(full), C.c_void_p),
                                   C.cast(C.byref(delta), C.c_void_p))
         return {"shards": n.value, "full_rebuilds": full.value, "delta_builds": delta.value,
-                "tombstoned_rows": int(N.host.orrh_service_tombstoned_rows(self._h))}
+                "tombstoned_rows": int(N.host.orrh_service_tombstoned_rows(self._h)),
+                "compactions": int(N.host.orrh_service_compactions(self._h))}
 
     def close(self):
         if self._h:

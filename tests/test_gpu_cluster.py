@@ -160,3 +160,27 @@ def test_cluster_deletes_after_the_seal_shift_the_candidate_limit_of_later_shard
         orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 8, candidate_limit=600)
         assert list(rows[b, :counts[b]]) == [keep[int(r)] for r in orow] and np.array_equal(scores[b, :counts[b]], osc), b
     cl.close()
+
+
+def test_cluster_compaction_moves_the_later_shards_up():
+    P = pkg()
+    rng = np.random.default_rng(613)
+    n, dim = 1500, 32
+    c = _sorted_corpus(rng, n, dim, p_null=0.0)
+    cl = P.RecallCluster([0, 0, 0], dim)
+    _fill(P, cl, c, [0, 500, 1000, n])
+    gone = set(int(x) for x in rng.choice(n, 300, replace=False))
+    for g, (lo, hi) in enumerate(((0, 500), (500, 1000), (1000, n))):
+        cl.shard(g).delete_rows(sorted(r for r in gone if lo <= r < hi))
+    assert cl.compact() == len(gone) and cl.rows == n - len(gone)
+    keep = [r for r in range(n) if r not in gone]
+    corpus = orc.OracleCorpus([c["emb"][r] for r in keep], c["created"][keep], [c["contents"][r] for r in keep])
+    qs = rng.standard_normal((5, dim)).astype(np.float32)
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(5)]
+    terms = [P.text.query_terms(t) for t in texts]
+    for topk, limit in ((10, n), (6, 420), (6, 800), (3, 1)):
+        rows, scores, counts = cl.search(qs, terms, NOW, topk, candidate_limit=limit)
+        for b in range(5):
+            orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=limit)
+            assert list(rows[b, :counts[b]]) == [keep[int(r)] for r in orow] and np.array_equal(scores[b, :counts[b]], osc), (topk, limit, b)
+    cl.close()

@@ -169,3 +169,79 @@ def test_deletes_across_two_shards_keep_the_global_candidate_limit():
             assert np.array_equal(scores[0, :counts[0]], osc)
     for p in parts:
         p.close()
+
+
+def test_compaction_in_place_equals_a_rebuilt_shard(tmp_path):
+    """orr_index_compact: the deleted rows leave the device arrays (embeddings moved up in place, scalars gathered, posting
+    lists renumbered, shadows rebuilt on demand); ids are kept; every search then equals the oracle over the surviving rows,
+    through the exact kernel, the streaming screen and the int8 GEMM; the quarter-of-the-shard limit is lifted; deletes,
+    a second compaction and a shard-file round trip work on the compacted shard."""
+    P = pkg()
+    rng = np.random.default_rng(41)
+    n, dim = 230_000, 128
+    emb = rng.standard_normal((n, dim)).astype(np.float32)
+    created = np.sort(NOW - rng.integers(0, 300 * DAY, n))[::-1].astype(np.int64)
+    words = np.array(["alpha", "beta", "gamma", "delta", "kubernetes", "helm", "azure", "cosmos"])
+    contents = [" ".join(w) for w in words[rng.integers(0, len(words), (n, 4))]]
+    ids = np.arange(n, dtype=np.int64) * 3 + 7                              # caller's ids, not positions
+    idx = P.RecallIndex(dim=dim)
+    for r0 in range(0, n, 50_000):
+        idx.append(emb[r0:r0 + 50_000], created[r0:r0 + 50_000], [s.encode() for s in contents[r0:r0 + 50_000]], row_ids=ids[r0:r0 + 50_000])
+    idx.seal()
+    B = 12
+    qs = rng.standard_normal((B, dim)).astype(np.float32)
+    texts = [TEXTS[b % len(TEXTS)] for b in range(B)]
+    terms = [P.text.query_terms(t) for t in texts]
+    idx.search(qs, terms, NOW, 10, candidate_limit=n)                        # (the int8 shadow exists before the rows move)
+    deleted = set()
+
+    def check(handle, what):
+        keep = np.array([r for r in range(n) if r not in deleted], dtype=np.int64)
+        corpus = orc.OracleCorpus(emb[keep], created[keep], [contents[r] for r in keep])
+        for limit in (len(keep), 150_000, 300):
+            rows, scores, counts = handle.search(qs, terms, NOW, 10, candidate_limit=limit)
+            for b in (0, 1, 5, 11):
+                orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 10, candidate_limit=limit, threads=8)
+                assert list(rows[b, :counts[b]]) == [int(ids[keep[r]]) for r in orow], (what, limit, b)
+                assert np.array_equal(scores[b, :counts[b]], osc), (what, limit, b)
+        r1, s1, c1 = handle.search(qs[:1], terms[:1], NOW, 10, candidate_limit=len(keep))       # streaming screen
+        rows, scores, counts = handle.search(qs, terms, NOW, 10, candidate_limit=len(keep))
+        assert np.array_equal(r1[0], rows[0]) and np.array_equal(s1[0], scores[0])
+        return rows
+
+    # a first wave: 20 % of the rows, among them whatever ranks first, the newest rows and a whole stretch
+    top = check(idx, "before")
+    victims = set(int((r - 7) // 3) for r in top[:, :3].ravel()) | set(range(0, 40)) | set(range(100_000, 100_700))
+    victims |= set(int(r) for r in rng.choice(n, n // 5, replace=False))
+    assert idx.delete_rows([int(ids[r]) for r in sorted(victims)]) == len(victims)
+    deleted |= victims
+    check(idx, "tombstoned")
+    # a second wave would pass a quarter of the shard: refused ...
+    more = set(int(r) for r in rng.choice(n, n // 10, replace=False)) - deleted
+    with pytest.raises(P.OrrError):
+        idx.delete_rows([int(ids[r]) for r in sorted(more)])
+    # ... until the shard is compacted
+    view = idx.view()
+    with pytest.raises(P.OrrError):                                         # a caller's view pins the arrays
+        idx.compact()
+    view.close()
+    assert idx.compact() == len(deleted)
+    assert idx.rows == n - len(deleted) and idx.live_rows == idx.rows
+    assert idx.compact() == 0
+    check(idx, "compacted")
+    assert idx.delete_rows([int(ids[r]) for r in sorted(more)]) == len(more)
+    deleted |= more
+    check(idx, "compacted + deleted")
+    idx.set_option("two_stage", 0)
+    check(idx, "compacted + deleted, exact kernel")
+    idx.set_option("two_stage", 1)
+    assert idx.compact() == len(more)
+    rows_final = check(idx, "compacted twice")
+    path = str(tmp_path / "compacted.orr")
+    idx.save(path)
+    idx.close()
+    again = P.RecallIndex.load(path)
+    assert again.rows == n - len(deleted)
+    r2, _, _ = again.search(qs, terms, NOW, 10, candidate_limit=again.rows)
+    assert np.array_equal(r2, rows_final)
+    again.close()

@@ -233,7 +233,7 @@ def test_uploads_after_the_first_build_become_delta_shards():
     for sut_limit in (300, 10**6):
         sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=sut_limit, now_ticks=NOW)
         check(sut)
-        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0, "tombstoned_rows": 0}
+        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0, "tombstoned_rows": 0, "compactions": 0}
         t = base_time + 10**9 * (1 if sut_limit == 300 else 5)
         for step in range(3):                                  # three rounds of newer uploads -> three delta shards
             for j in range(2):
@@ -270,6 +270,56 @@ def test_uploads_after_the_first_build_become_delta_shards():
         upload("old-03", base_time + 3 * 1000 + 1)
         for g in gone:
             upload(g, base_time + int(g[4:]) * 1000 + 1)
+    store.close()
+
+
+@pytest.mark.gpu
+def test_deletes_past_a_quarter_of_a_shard_compact_it_instead_of_rebuilding():
+    """Two waves of deleted documents, each a fifth of the store: the second would take the shard past a quarter of
+    tombstones, so the mirror compacts it in place (orr_index_compact: the first wave's rows leave the device arrays, ids
+    stay) and drops the second wave's rows -- no rebuild, results still the oracle's over the surviving chunks."""
+    S = _svc()
+    rng = np.random.default_rng(57)
+    store = S.InMemoryIngestionStore()
+    words = ["alpha", "beta", "gamma", "delta", "kubernetes", "azure"]
+    chunks_flat = []
+    base_time = NOW - 50 * 864000000000
+    for d in range(40):
+        doc = "doc-%02d" % d
+        store.UpsertDocument(S.CosmosDocumentRecord(doc, doc + ".md", base_time + d * 1000))
+        cs = [S.CosmosChunkRecord("%s:%04d" % (doc, i), doc, i, " ".join(rng.choice(words, 8)),
+                                  rng.standard_normal(16).astype(np.float32), base_time + d * 1000) for i in range(5)]
+        store.UpsertChunks(cs)
+        chunks_flat.extend(cs)
+    qv = rng.standard_normal(16).astype(np.float32)
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=10**6, now_ticks=NOW)
+
+    def check(limit_note):
+        cor = orc.OracleCorpus([c.Embedding for c in chunks_flat], [c.CreatedAtTicks for c in chunks_flat], [c.Content for c in chunks_flat])
+        for text in ("alpha kubernetes", "the gamma", "zzz"):
+            body = sut.Search(text, 9)
+            rows, _, rounded = cor.search(qv, text, NOW, 9, candidate_limit=10**6)
+            assert [(c["chunkId"], c["score"]) for c in body["citations"]] == [(chunks_flat[r].Id, rd) for r, rd in zip(rows, rounded)], limit_note
+
+    check("built")
+    for wave, docs in enumerate((range(0, 40, 5), range(1, 40, 5))):       # 8 documents = 20 % of the rows each
+        for d in docs:
+            store.DeleteDocument("doc-%02d" % d)
+        gone = {"doc-%02d" % d for d in docs}
+        chunks_flat[:] = [c for c in chunks_flat if c.DocumentId not in gone]
+        check("wave %d" % wave)
+    st = sut.Stats()
+    assert st["full_rebuilds"] == 1 and st["compactions"] == 1 and st["tombstoned_rows"] == 80 and st["shards"] == 1, st
+    # newer uploads still become delta shards in front of the compacted one
+    doc = "doc-new"
+    store.UpsertDocument(S.CosmosDocumentRecord(doc, doc + ".md", NOW - 1000))
+    cs = [S.CosmosChunkRecord("%s:%04d" % (doc, i), doc, i, "alpha kubernetes " + " ".join(rng.choice(words, 4)),
+                              rng.standard_normal(16).astype(np.float32), NOW - 1000) for i in range(3)]
+    store.UpsertChunks(cs)
+    chunks_flat.extend(cs)
+    check("delta shard in front of a compacted shard")
+    assert sut.Stats()["shards"] == 2 and sut.Stats()["full_rebuilds"] == 1
+    sut.close()
     store.close()
 
 
