@@ -162,6 +162,12 @@ struct orr_index {
     // matched one lane per token.  Built at the first search with terms (ensure_vlong); -1 = not yet.
     int64_t n_vlong = -1;
     DevBuf vlong_start, vlong_len, vlong_id;
+    // stored row bitmaps of the FREQUENT vocabulary tokens (a posting list of at least rows / 64 entries: the bitmap is at most
+    // twice its bytes), built at the first search with terms over a large shard (ensure_token_bitmaps): a query term whose only
+    // hit is such a token uses the stored bitmap as it is instead of expanding the posting list again for every batch
+    int64_t n_tok_bm = -1;             // -1: not looked at yet; 0: none
+    int64_t tok_bm_words = 0;
+    DevBuf tok_bm, tok_bm_index;       // [n_tok_bm][tok_bm_words] u32; [n_tokens] int32 bitmap number or -1
     std::vector<int64_t> h_created;    // host mirror (seal-time ordering)
     std::vector<uint32_t> h_clen;      // host mirror of content lengths
     std::vector<uint64_t> h_cprefix;   // after seal: bytes of content in rows [0, r)
@@ -192,7 +198,7 @@ struct orr_index {
     // search workspace
     DevBuf ws_q, ws_dot, ws_dotf, ws_sel, ws_cand, ws_qc, ws_rowc, ws_tau, ws_qsplit, ws_fcnt, ws_fbuf, ws_fqf, ws_fany, ws_tsL, ws_tskey, ws_qtiled, ws_fdot, ws_pbuf, ws_psel, ws_q8, ws_q8s1, ws_q8err, ws_zero, ws_norm_a;
     DevBuf ws_keys_a, ws_keys_b, ws_vals_a, ws_vals_b, ws_sort_tmp, ws_raw, ws_src_start, ws_qsub;
-    DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta, ws_tickets;
+    DevBuf ws_vmatch, ws_bitmaps, ws_hits, ws_counter, ws_meta, ws_tickets, ws_kwalias;
     size_t bitmaps_clean = 0;          // leading bytes of ws_bitmaps known to be zero (cleared again behind every search)
     const void *bitmaps_clean_of = nullptr;
     PinnedBuf pin_meta, pin_q, pin_qc, pin_cand, pin_norm, pin_cnt, pin_kwcnt;
@@ -709,15 +715,16 @@ void orr_index_destroy(orr_index *idx)
         if (idx->d_post_rows) (void)hipFree(idx->d_post_rows);
     } else {
         idx->emb_shadow.p = nullptr; idx->emb_shadow.cap = 0;
-        for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat, &idx->i8_rowf}) { b->p = nullptr; b->cap = 0; }
+        for (DevBuf *b : {&idx->emb_i8, &idx->i8_scale, &idx->i8_rel_err, &idx->i8_rel_hat, &idx->i8_rowf, &idx->tok_bm, &idx->tok_bm_index}) { b->p = nullptr; b->cap = 0; }
     }
+    idx->tok_bm.release(); idx->tok_bm_index.release();
     idx->d_dead.release();
     if (!idx->is_view) { idx->vlong_start.release(); idx->vlong_len.release(); idx->vlong_id.release(); }
     idx->ws_norm_a.release();
     DevBuf *bufs[] = {&idx->ws_q, &idx->ws_dot, &idx->ws_dotf, &idx->ws_rowc, &idx->ws_tau, &idx->ws_qsplit, &idx->ws_fcnt,
                       &idx->ws_fbuf, &idx->ws_fqf, &idx->ws_fany, &idx->ws_tsL, &idx->ws_tskey, &idx->ws_qtiled, &idx->ws_fdot, &idx->ws_pbuf, &idx->ws_psel, &idx->ws_q8, &idx->ws_q8s1, &idx->ws_q8err, &idx->ws_zero, &idx->ws_sel, &idx->ws_cand, &idx->ws_qc, &idx->ws_keys_a, &idx->ws_keys_b,
                       &idx->ws_vals_a, &idx->ws_vals_b, &idx->ws_sort_tmp, &idx->ws_raw, &idx->ws_src_start, &idx->ws_qsub,
-                      &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta, &idx->ws_tickets};
+                      &idx->ws_vmatch, &idx->ws_bitmaps, &idx->ws_hits, &idx->ws_counter, &idx->ws_meta, &idx->ws_tickets, &idx->ws_kwalias};
     for (auto b : bufs) b->release();
     idx->emb_shadow.release();
     idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
@@ -1201,6 +1208,63 @@ static int ensure_vlong(orr_index *idx)
     return ORR_OK;
 }
 
+// Row bitmaps of the frequent vocabulary tokens (see orr_index::tok_bm), through the same posting expansion a batch runs.
+static int ensure_token_bitmaps(orr_index *idx)
+{
+    if (idx->is_view || idx->n_tok_bm >= 0 || !idx->sealed) return ORR_OK;    // a view copies its parent's at creation
+    idx->n_tok_bm = 0;
+    if (const char *e = getenv("ORR_TOKEN_BITMAPS")) { if (atoi(e) == 0) return ORR_OK; }      // diagnostic: A/B against per-batch expansion
+    const int64_t n = idx->n_rows, V = idx->n_tokens;
+    if (n < 48 * (int64_t)orr::kSelSegRows || V <= 0 || idx->n_postings == 0) return ORR_OK;   // small shards expand in microseconds
+    const int64_t words = ((n + 31) / 32 + 3) / 4 * 4;
+    std::vector<uint64_t> off((size_t)V + 1);
+    HIP_TRY(hipMemcpy(off.data(), idx->d_post_off, sizeof(uint64_t) * ((size_t)V + 1), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> toks;
+    for (int64_t v = 0; v < V; ++v)
+        if ((off[(size_t)v + 1] - off[(size_t)v]) * 64 >= (uint64_t)n) toks.push_back((uint32_t)v);
+    if (toks.empty()) return ORR_OK;
+    const size_t bytes = toks.size() * (size_t)words * sizeof(uint32_t);
+    size_t free_b = 0, total_b = 0;
+    if (bytes > ((size_t)32 << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)12 << 30)) return ORR_OK;   // no room: expand per batch
+    if (idx->tok_bm.reserve(bytes) != ORR_OK || idx->tok_bm_index.reserve(sizeof(int32_t) * (size_t)V) != ORR_OK) {
+        (void)hipGetLastError();
+        idx->tok_bm.release(); idx->tok_bm_index.release();
+        return ORR_OK;
+    }
+    std::vector<int32_t> index((size_t)V, -1);
+    std::vector<orr::KwHit> hits(toks.size());
+    uint64_t chunks = 0;
+    for (size_t j = 0; j < toks.size(); ++j) {
+        const uint32_t v = toks[j];
+        index[v] = (int32_t)j;
+        orr::KwHit h;
+        h.post_begin = off[v]; h.post_len = (uint32_t)(off[(size_t)v + 1] - off[v]); h.chunk_base = (uint32_t)chunks; h.term = (uint32_t)j; h.token = v;
+        hits[j] = h;
+        chunks += (h.post_len + orr::kPostChunk - 1) / orr::kPostChunk;
+    }
+    if (chunks >= ((uint64_t)1 << 32)) { idx->tok_bm.release(); idx->tok_bm_index.release(); return ORR_OK; }
+    const unsigned long long counter = ((unsigned long long)toks.size() << 32) | (unsigned long long)chunks;
+    DevBuf d_hits, d_counter;
+    ORR_TRY(d_hits.reserve(sizeof(orr::KwHit) * hits.size()));
+    ORR_TRY(d_counter.reserve(sizeof(counter)));
+    hipStream_t s = idx->stream;
+    hipError_t e = hipMemcpyAsync(d_hits.p, hits.data(), sizeof(orr::KwHit) * hits.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_counter.p, &counter, sizeof(counter), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(idx->tok_bm_index.p, index.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(idx->tok_bm.p, 0, bytes, s);
+    if (e == hipSuccess) e = orr::launch_expand_hits(d_hits.as<orr::KwHit>(), d_counter.as<unsigned long long>(), (uint32_t)hits.size(), idx->d_post_rows,
+                                                     idx->tok_bm.as<uint32_t>(), words, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    d_hits.release(); d_counter.release();
+    if (e != hipSuccess) {
+        idx->tok_bm.release(); idx->tok_bm_index.release();
+        return fail(ORR_EDEVICE, "token bitmaps: %s", hipGetErrorString(e));
+    }
+    idx->n_tok_bm = (int64_t)toks.size();
+    idx->tok_bm_words = words;
+    return ORR_OK;
+}
+
 int64_t orr_index_live_rows(const orr_index *idx)
 {
     return idx ? idx->n_rows - (int64_t)(idx->parent ? idx->parent->dead.size() : idx->dead.size()) : 0;
@@ -1369,6 +1433,7 @@ int orr_index_compact(orr_index *idx, int64_t *out_removed)
     idx->emb_i8.release(); idx->i8_scale.release(); idx->i8_rel_err.release(); idx->i8_rel_hat.release(); idx->i8_rowf.release();
     idx->i8_ready = false; idx->i8_failed = false;
     idx->bitmaps_clean = 0; idx->bitmaps_clean_of = nullptr;
+    idx->tok_bm.release(); idx->tok_bm_index.release(); idx->n_tok_bm = -1; idx->tok_bm_words = 0;
     {
         std::lock_guard<std::mutex> ll(idx->lanes_mu);
         old_lanes.swap(idx->lanes);
@@ -1453,10 +1518,13 @@ static int make_view(orr_index *parent, orr_index **out, bool internal)
         if (!parent->i8_ready) ORR_TRY(ensure_shadow(parent));
     }
     ORR_TRY(ensure_vlong(parent));             // (before the view exists: a failure here must not leak it)
+    ORR_TRY(ensure_token_bitmaps(parent));
     orr_index *v = new (std::nothrow) orr_index();
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
     v->n_vlong = parent->n_vlong;
+    v->n_tok_bm = parent->n_tok_bm; v->tok_bm_words = parent->tok_bm_words;
+    v->tok_bm.p = parent->tok_bm.p; v->tok_bm_index.p = parent->tok_bm_index.p;                                        // borrowed
     v->vlong_start.p = parent->vlong_start.p; v->vlong_len.p = parent->vlong_len.p; v->vlong_id.p = parent->vlong_id.p;   // borrowed
     v->parent = parent; v->dead_before = parent->dead_before;
     v->device = parent->device; v->dim = parent->dim; v->row_base = parent->row_base;
@@ -1846,7 +1914,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     // ---- K3 keyword side first, on its own stream (with the int8 prefix the main stream has little to do before it
     // needs the bitmaps, so this chain is the critical path of a batch): distinct terms -> vocabulary scan -> posting lists
     // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
-    orr::KwView kw{nullptr, 0, nullptr, nullptr};
+    orr::KwView kw{nullptr, 0, nullptr, nullptr, nullptr};
     size_t bm_bytes = 0, bm_clean_before = 0;
     bool kw_overflow_possible = false;
     uint32_t kw_max_hits = 0;
@@ -1918,6 +1986,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
         const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, idx->kw_hits_cap);
         ORR_TRY(ensure_vlong(idx));
+        ORR_TRY(ensure_token_bitmaps(idx));
         const int64_t VL = idx->n_vlong;
         ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
         ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
@@ -1960,11 +2029,26 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                    idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
                 }
             }
+            // terms whose only hit is a token with a stored bitmap use that bitmap as it is (no expansion, nothing copied)
+            const uint8_t *skip = nullptr;
+            if (idx->n_tok_bm > 0 && idx->tok_bm_words == words) {
+                const size_t o_tok = sizeof(uint32_t) * (size_t)TT, o_off = (2 * o_tok + 7) / 8 * 8, o_alias = o_off + sizeof(int64_t) * (size_t)TT;
+                ORR_TRY(idx->ws_kwalias.reserve(o_alias + (size_t)TT + 16));
+                uint8_t *wa = idx->ws_kwalias.as<uint8_t>();
+                HIP_TRY(hipMemsetAsync(wa, 0, o_tok, k));                  // the hit counts
+                const int64_t delta = (int64_t)(idx->tok_bm.as<uint32_t>() - idx->ws_bitmaps.as<uint32_t>());   // words from the batch's bitmaps to the token store
+                Timed t(idx, "kw_alias", 0.0, k);
+                HIP_TRY(orr::launch_kw_alias(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits, (int32_t)TT,
+                                             idx->tok_bm_index.as<int32_t>(), delta, words, reinterpret_cast<uint32_t *>(wa),
+                                             reinterpret_cast<uint32_t *>(wa + o_tok), reinterpret_cast<int64_t *>(wa + o_off), wa + o_alias, k));
+                kw.term_word_off = reinterpret_cast<const int64_t *>(wa + o_off);
+                skip = wa + o_alias;
+            }
             {
                 Timed t(idx, "expand_hits", 0.0, k);
                 HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
                                                 idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k,
-                                                idx->pin_kwcnt.as<unsigned long long>()));     // hits of this pass: statistics
+                                                idx->pin_kwcnt.as<unsigned long long>(), skip));     // hits of this pass: statistics
             }
         }
         HIP_TRY(hipEventRecord(idx->ev_kw_done, k));

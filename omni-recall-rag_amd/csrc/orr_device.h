@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t kw_matches(const KwView &kw, int b, uint32_t
     uint32_t m = 0;
     const uint32_t t0 = kw.q_term_off[b], t1 = kw.q_term_off[b + 1];
     for (uint32_t i = t0; i < t1; ++i) {
-        const uint32_t word = kw.bitmaps[(int64_t)kw.q_term_idx[i] * kw.words_per_term + (row >> 5)];
+        const uint32_t word = kw.bitmaps[kw_term_base(kw, kw.q_term_idx[i]) + (row >> 5)];
         m += (word >> (row & 31)) & 1u;
     }
     return m;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int3
             for (int p = 0; p < kCountPlanes; ++p) c[k][p] = 0u;
         if (Q < n_quads) {
             for (uint32_t i = t0; i < t1; ++i) {
-                const uint4 w4 = *reinterpret_cast<const uint4 *>(kw.bitmaps + (int64_t)kw.q_term_idx[i] * kw.words_per_term + Q * 4);
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(kw.bitmaps + kw_term_base(kw, kw.q_term_idx[i]) + Q * 4);
                 const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {

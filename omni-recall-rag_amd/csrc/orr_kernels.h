@@ -100,13 +100,23 @@ struct KwView {
     int64_t words_per_term;
     const uint32_t *q_term_idx;    // [sum of query term counts]
     const uint32_t *q_term_off;    // [B+1]
+    // Where distinct term t's bitmap starts, in words from `bitmaps` (null: t * words_per_term).  A term whose only hit is a
+    // vocabulary token with a STORED bitmap (orr_index: built once per sealed shard for the frequent tokens) points straight at
+    // that bitmap -- the offset then leads out of the batch's own bitmaps into the token store, nothing is expanded or copied.
+    const int64_t *term_word_off;
 };
+__host__ __device__ inline int64_t kw_term_base(const KwView &kw, uint32_t t)
+{
+    return kw.term_word_off ? kw.term_word_off[t] : (int64_t)t * kw.words_per_term;
+}
 
 // One (term, token) match: the token's posting run and where its 1024-posting chunks start.
 struct KwHit {
-    uint64_t post_begin, post_end;
+    uint64_t post_begin;
+    uint32_t post_len;      // postings of the token (a shard holds fewer than 2^32 rows)
     uint32_t chunk_base;
     uint32_t term;
+    uint32_t token;         // vocabulary token of the hit (launch_kw_alias: a term whose ONLY hit is a token with a stored bitmap needs no expansion)
 };
 constexpr uint32_t kPostChunk = 1024;
 
@@ -126,9 +136,16 @@ hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart
                                     const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
                                     unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
 // counter_host (optional, pinned host memory): receives *counter (hits << 32 | chunks) for the caller's statistics.
+// skip_term (optional, [terms]): hits of terms flagged there are left out (their bitmaps are aliases, launch_kw_alias).
 hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
                               const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s,
-                              unsigned long long *counter_host = nullptr);
+                              unsigned long long *counter_host = nullptr, const uint8_t *skip_term = nullptr);
+// Decides per distinct term of a batch whether its bitmap can be an ALIAS of a stored token bitmap: exactly one (term, token)
+// hit, and that token has a stored bitmap (tok_bm_index[token] >= 0: bitmap number in a store that begins bm_store_delta
+// words from the batch's bitmaps).  term_cnt [n_terms] must be zero on entry.  Out: term_word_off [n_terms], alias [n_terms].
+hipError_t launch_kw_alias(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits, int32_t n_terms,
+                           const int32_t *tok_bm_index, int64_t bm_store_delta, int64_t words_per_term, uint32_t *term_cnt,
+                           uint32_t *term_tok, int64_t *term_word_off, uint8_t *alias, hipStream_t s);
 
 // Per-query constants of the fused score.
 struct QueryConst {

@@ -392,17 +392,53 @@ __global__ __launch_bounds__(256) void vocab_hits_kernel(const uint16_t *__restr
         const uint32_t slot = (uint32_t)(old >> 32);
         if (slot < max_hits) {
             KwHit h;
-            h.post_begin = p0; h.post_end = p1; h.chunk_base = (uint32_t)old; h.term = (uint32_t)t;
+            h.post_begin = p0; h.post_len = (uint32_t)(p1 - p0); h.chunk_base = (uint32_t)old; h.term = (uint32_t)t; h.token = (uint32_t)v;
             hits[slot] = h;
         }
     }
+}
+
+// One thread per hit: how many hits each distinct term has, and (for the terms with one) which token it was.
+__global__ __launch_bounds__(256) void kw_term_hits_kernel(const KwHit *__restrict__ hits, const unsigned long long *__restrict__ counter,
+                                                           uint32_t max_hits, uint32_t *__restrict__ term_cnt, uint32_t *__restrict__ term_tok)
+{
+    uint32_t n_hits = (uint32_t)(*counter >> 32);
+    if (n_hits > max_hits) n_hits = max_hits;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += gridDim.x * blockDim.x) {
+        const KwHit h = hits[i];
+        atomicAdd(&term_cnt[h.term], 1u);
+        term_tok[h.term] = h.token;                    // (the only writer where the count ends up 1)
+    }
+}
+
+__global__ __launch_bounds__(256) void kw_alias_kernel(const uint32_t *__restrict__ term_cnt, const uint32_t *__restrict__ term_tok,
+                                                       const int32_t *__restrict__ tok_bm_index, int32_t n_terms, int64_t bm_store_delta,
+                                                       int64_t words_per_term, int64_t *__restrict__ term_word_off, uint8_t *__restrict__ alias)
+{
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms) return;
+    int32_t bm = -1;
+    if (term_cnt[t] == 1u && tok_bm_index) bm = tok_bm_index[term_tok[t]];
+    alias[t] = bm >= 0 ? 1 : 0;
+    term_word_off[t] = bm >= 0 ? bm_store_delta + (int64_t)bm * words_per_term : (int64_t)t * words_per_term;
+}
+
+hipError_t launch_kw_alias(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits, int32_t n_terms,
+                           const int32_t *tok_bm_index, int64_t bm_store_delta, int64_t words_per_term, uint32_t *term_cnt,
+                           uint32_t *term_tok, int64_t *term_word_off, uint8_t *alias, hipStream_t s)
+{
+    if (n_terms <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kw_term_hits_kernel, dim3(64), dim3(256), 0, s, hits, counter, max_hits, term_cnt, term_tok);
+    hipLaunchKernelGGL(kw_alias_kernel, dim3((unsigned)((n_terms + 255) / 256)), dim3(256), 0, s, term_cnt, term_tok, tok_bm_index, n_terms,
+                       bm_store_delta, words_per_term, term_word_off, alias);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restrict__ hits,
                                                           const unsigned long long *__restrict__ counter,
                                                           uint32_t max_hits, const uint32_t *__restrict__ post_rows,
                                                           uint32_t *__restrict__ bitmaps, int64_t words_per_term,
-                                                          unsigned long long *__restrict__ counter_host)
+                                                          unsigned long long *__restrict__ counter_host, const uint8_t *__restrict__ skip_term)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long cnt = *counter;
@@ -419,8 +455,10 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restric
             if (hits[mid].chunk_base <= c) lo = mid; else hi = mid;
         }
         const KwHit h = hits[lo];
+        if (skip_term && skip_term[h.term]) continue;   // the term's bitmap is a stored token bitmap: nothing to expand
+        const uint64_t post_end = h.post_begin + h.post_len;
         const uint64_t b0 = h.post_begin + (uint64_t)(c - h.chunk_base) * kPostChunk;
-        const uint64_t b1 = b0 + kPostChunk < h.post_end ? b0 + kPostChunk : h.post_end;
+        const uint64_t b1 = b0 + kPostChunk < post_end ? b0 + kPostChunk : post_end;
         uint32_t *bm = bitmaps + (int64_t)h.term * words_per_term;
         // posting rows ascend, so the lanes that hit one bitmap word are neighbours: OR their bits
         // together (segmented, 5 steps: a word has 32 bits) and let the last lane of each run do the atomic
@@ -520,7 +558,7 @@ __global__ __launch_bounds__(256) void vocab_match_short_kernel(const uint8_t *_
         const uint32_t slot = (uint32_t)(old >> 32);
         if (slot < max_hits) {
             KwHit h;
-            h.post_begin = p0; h.post_end = p1; h.chunk_base = (uint32_t)old; h.term = (uint32_t)t;
+            h.post_begin = p0; h.post_len = (uint32_t)(p1 - p0); h.chunk_base = (uint32_t)old; h.term = (uint32_t)t; h.token = (uint32_t)v;
             hits[slot] = h;
         }
     }
@@ -541,10 +579,10 @@ hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart
 
 hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,
                               const uint32_t *post_rows, uint32_t *bitmaps, int64_t words_per_term, hipStream_t s,
-                              unsigned long long *counter_host)
+                              unsigned long long *counter_host, const uint8_t *skip_term)
 {
     hipLaunchKernelGGL(expand_hits_kernel, dim3(1024), dim3(256), 0, s, hits, counter, max_hits, post_rows, bitmaps,
-                       words_per_term, counter_host);
+                       words_per_term, counter_host, skip_term);
     return hipGetLastError();
 }
 
