@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="ranks", choices=["ranks", "cluster"],
                     help="several GPUs: 'ranks' = one process per GPU + RCCL (torch.distributed; what the driver launches); 'cluster' = ONE "
                          "process driving all --gpus devices through orr_cluster_search_batch (the form a C# host loads, INTEGRATION.md 5a)")
+    ap.add_argument("--cluster-exchange", default="host", choices=["host", "rccl"],
+                    help="--mode cluster: how the per-shard records reach the merge: pinned host memory (default) or ONE RCCL all-gather "
+                         "(orr_cluster_set_option exchange=1)")
     ap.add_argument("--cluster-oversubscribe", action="store_true",
                     help="rehearsal only: --mode cluster with more shards than visible devices (shards share cards, device g %% visible)")
     ap.add_argument("--strong-rows", type=int, default=10_000_000, help="total rows of the fixed-N (strong-scaling) leg of a multi-GPU run; 0 = skip")
@@ -456,7 +459,23 @@ def oracle_leg(args, env, idx, gen, n_total, B_headline, probe):
 
 
 
-def run_cluster_leg(args, env, gen, devices, rows_per_dev, B, terms=True, workload=None):
+def cluster_child(args, n_dev):
+    """`bench.py --mode cluster --cluster-exchange rccl` over the same devices as a child process; its compact line comes back as the leg."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_dev), "--mode", "cluster", "--cluster-exchange", "rccl",
+           "--rows-per-gpu", str(args.cluster_leg_rows), "--batch", "256", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--dim", str(args.dim), "--topk", str(args.topk), "--no-legs", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if not lines:
+        raise RuntimeError("child rc %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-200:]))
+    doc = json.loads(lines[-1])
+    if doc.get("error") or p.returncode != 0:
+        raise RuntimeError("child rc %d: %s" % (p.returncode, doc.get("error")))
+    return {"workload": doc["config"]["workload"], "value": doc["value"], "unit": "queries/s", "ms_per_step": doc["ms_per_step"],
+            "rank1_is_planted_row": doc.get("rank1_is_planted_row"), "rccl_exchanges": doc.get("rccl_exchanges"), "child_total_s": doc.get("total_s")}
+
+
+def run_cluster_leg(args, env, gen, devices, rows_per_dev, B, terms=True, workload=None, exchange="host"):
     """ONE process, every device: orr_cluster (one shard per device, a host thread per shard, records through pinned host
     memory, host merge) -- the multi-GPU form of the C ABI that a C# host binds.  Queries are host-resident by contract."""
     P, torch = env["P"], env["torch"]
@@ -479,6 +498,8 @@ def run_cluster_leg(args, env, gen, devices, rows_per_dev, B, terms=True, worklo
                 torch.cuda.current_stream().synchronize()
                 sh.append(emb, created, pool, off, row_ids=ids)
     cl.seal()
+    if exchange == "rccl":
+        cl.set_option("exchange", 1)
     setup = time.perf_counter() - t0
     n_steps_total = args.warmup + args.steps
     q_steps, term_steps = [], []
@@ -501,7 +522,10 @@ def run_cluster_leg(args, env, gen, devices, rows_per_dev, B, terms=True, worklo
            "value": args.steps * B / dt, "unit": "queries/s", "ms_per_step": 1e3 * dt / args.steps, "queries_per_step": B,
            "corpus_rows": n_total, "devices": G, "rank1_is_planted_row": [int(r) for r in last[0][:, 0]] == planted,
            "search_stats": cl.search_stats(), "setup_s": round(setup, 2),
-           "exchange": "per-shard [B][k'+1] candidate records through pinned host memory, host merge (no collective: one address space)"}
+           "exchange": ("ONE ncclAllGather (RCCL over xGMI) of the per-shard [B][k'+1] candidate records per pass, merge from device 0's copy"
+                        if exchange == "rccl" else
+                        "per-shard [B][k'+1] candidate records through pinned host memory, host merge (no collective: one address space)")}
+    res["rccl_exchanges"] = res["search_stats"].get("rccl_exchanges", 0)
     cl.close()
     return res
 
@@ -552,7 +576,7 @@ def compact_line(out, full_path=None):
         c["cpu_baseline"] = None
     if out.get("parity"):
         c["parity"] = _pick(out["parity"], ("rank_identical", "max_abs_score_delta", "rows_checked", "queries_checked", "candidate_limit"))
-    for k in ("rank1_is_planted_row", "rccl_ranks_seen", "collectives_per_step", "backend", "error"):
+    for k in ("rank1_is_planted_row", "rccl_ranks_seen", "collectives_per_step", "backend", "exchange_mode", "rccl_exchanges", "error"):
         if k in out:
             c[k] = _r(out[k])
     if isinstance(out.get("two_steps_in_flight"), dict) and "value" in out["two_steps_in_flight"]:
@@ -689,7 +713,9 @@ def run(args, probe, state, cluster_mode, world, rank):
         B = args.batch or 1024
         n_total = rows * args.gpus
         head = run_cluster_leg(args, env, syn, [g % max(1, n_visible) for g in range(args.gpus)], rows, B, terms=not args.no_terms,
-                               workload=workload_label(rows, dim, B, k, not args.no_terms, args.gpus).replace("row-sharded over", "orr_cluster, one process, over"))
+                               workload=workload_label(rows, dim, B, k, not args.no_terms, args.gpus).replace("row-sharded over", "orr_cluster, one process, over"),
+                               exchange=args.cluster_exchange)
+        head["exchange_mode"] = args.cluster_exchange
         head["row_scores_per_sec"] = head["value"] * n_total
         if n_visible < args.gpus:
             head["workload"] += " [REHEARSAL: %d shards on %d card(s)]" % (args.gpus, n_visible)
@@ -774,9 +800,12 @@ def run(args, probe, state, cluster_mode, world, rank):
         # shards: every device already holds its rank's 12.5M rows.
         if not args.no_legs and args.cluster_leg_rows > 0 and args.backend == "nccl":
             if rank == 0:
-                optional_leg("cluster_one_process_%dM_rows_per_device_256_queries" % max(1, args.cluster_leg_rows // 1_000_000),
-                             lambda: run_cluster_leg(args, env, syn, list(range(world)), args.cluster_leg_rows, 256))
+                tag = "cluster_one_process_%dM_rows_per_device_256_queries" % max(1, args.cluster_leg_rows // 1_000_000)
+                optional_leg(tag, lambda: run_cluster_leg(args, env, syn, list(range(world)), args.cluster_leg_rows, 256))
                 torch.cuda.set_device(dev_index)
+                # the same with the records exchanged by ONE RCCL all-gather (orr_cluster "exchange" = 1) -- in a CHILD process: that
+                # path has never run on more than one device, and whatever it does must not take this job's record down with it
+                optional_leg(tag + "_rccl_exchange", lambda: cluster_child(args, world))
             dist.barrier()
 
     cpu = parity = None
@@ -825,7 +854,7 @@ def assemble(args, probe, head, legs_out, setup_s, cpu, parity, rows, n_total, B
         "setup_s": {kk: round(v, 2) for kk, v in setup_s.items()},
         "total_s": round(time.perf_counter() - t_start, 2),
     }
-    for extra in ("rccl_ranks_seen", "collectives_per_step", "backend", "two_steps_in_flight", "escalated_queries"):
+    for extra in ("rccl_ranks_seen", "collectives_per_step", "backend", "two_steps_in_flight", "escalated_queries", "exchange_mode", "rccl_exchanges"):
         if extra in head:
             out[extra] = head[extra]
     if leg_errors:

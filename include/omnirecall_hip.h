@@ -120,7 +120,7 @@ typedef struct orr_search_stats {
                                     large-k sort); 1 two-stage on the int8 shadow; 2 two-stage on the bf16 shadow; 3 two-stage
                                     WITHOUT a shadow (fp32 rows converted inside the kernel: "two_stage" = 2, or the shadow
                                     did not fit in device memory and "two_stage" = 1 fell back)                          */
-    int64_t reserved[1];
+    int64_t reserved[1];         /* orr_cluster_search_stats: record exchanges done by RCCL all-gather ("exchange" = 1)      */
 } orr_search_stats;
 
 int         orr_abi_version(void);
@@ -364,6 +364,16 @@ int        orr_cluster_search_batch(orr_cluster *c, int32_t B, int32_t dim, cons
                                     int64_t candidate_limit, int64_t *out_rows, double *out_scores,
                                     int32_t *out_counts);
 int        orr_cluster_search_stats(orr_cluster *c, orr_search_stats *out, int32_t reset);
+/* Integer options of a cluster; unknown names are ORR_EINVAL.
+ *   "exchange"   0 (default): the per-shard [B][k'+1] candidate records come back through pinned host memory (every record is
+ *                wanted in ONE address space, so nothing needs a collective); 1: every shard writes its records into a
+ *                device buffer and ONE RCCL all-gather over xGMI (ncclAllGather, one communicator per shard device, grouped
+ *                from one thread) brings all shards' records to every device; the merge reads device 0's gathered copy --
+ *                the literal exchange of BASELINE.json's north_star in the form a single-process host can load.  librccl.so is
+ *                bound at run time (dlopen): ORR_ECOMM when it cannot be loaded, ORR_EINVAL when two shards share a device
+ *                (a communicator needs distinct devices).  A failure of a later collective switches the cluster back to 0
+ *                and returns ORR_ECOMM for that search. */
+int        orr_cluster_set_option(orr_cluster *c, const char *name, int64_t value);
 /* orr_index_compact on every shard (concurrently), then the shards are placed in the global order again. */
 int        orr_cluster_compact(orr_cluster *c, int64_t *out_removed);
 

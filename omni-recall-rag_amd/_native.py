@@ -126,6 +126,8 @@ hip.orr_cluster_rows.restype = _i64
 hip.orr_cluster_rows.argtypes = [_vp]
 hip.orr_cluster_search_batch.restype = C.c_int
 hip.orr_cluster_search_batch.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]
+hip.orr_cluster_set_option.restype = C.c_int
+hip.orr_cluster_set_option.argtypes = [_vp, C.c_char_p, _i64]
 hip.orr_cluster_search_stats.restype = C.c_int
 hip.orr_cluster_search_stats.argtypes = [_vp, C.POINTER(OrrSearchStats), _i32]
 
@@ -200,7 +202,7 @@ EXPORTED_HIP_SYMBOLS = [
     "orr_index_save", "orr_index_load", "orr_index_set_row_base", "orr_index_set_option", "orr_index_screen_dots", "orr_index_screen_i8_dots", "orr_index_view",
     "orr_index_delete_rows", "orr_index_live_rows", "orr_index_compact", "orr_cluster_compact", "orr_index_search_stats",
     "orr_cluster_create", "orr_cluster_destroy", "orr_cluster_shards", "orr_cluster_shard", "orr_cluster_seal", "orr_cluster_rows",
-    "orr_cluster_search_batch", "orr_cluster_search_stats",
+    "orr_cluster_search_batch", "orr_cluster_search_stats", "orr_cluster_set_option",
 ]
 EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_terms", "orrh_build_snippet",
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <chrono>
 #include <pthread.h>
+#include <dlfcn.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -3077,6 +3078,39 @@ int orr_search_batch(orr_index *idx, int32_t B, int32_t dim, const float *q, con
 // does -- the record exchange of the multi-process path (RCCL all-gather, sharded.py) without the collective, because
 // here every record is wanted in ONE address space.  Escalation is per query, as in orr_search_batch.
 // ---------------------------------------------------------------------------------------------------------------------
+// RCCL, bound at run time (dlopen: the library stays loadable without it, and the default record exchange does not use it).
+// Declarations as in <rccl/rccl.h> (NCCL-compatible ABI): opaque communicator, int result (0 = success), ncclInt8 = 0.
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    static RcclApi *get()
+    {
+        static RcclApi *api = [] {
+            RcclApi *a = new RcclApi();
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                a->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (a->lib) break;
+            }
+            if (!a->lib) return a;
+            a->CommInitAll = reinterpret_cast<decltype(a->CommInitAll)>(dlsym(a->lib, "ncclCommInitAll"));
+            a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(dlsym(a->lib, "ncclCommDestroy"));
+            a->AllGather = reinterpret_cast<decltype(a->AllGather)>(dlsym(a->lib, "ncclAllGather"));
+            a->GroupStart = reinterpret_cast<decltype(a->GroupStart)>(dlsym(a->lib, "ncclGroupStart"));
+            a->GroupEnd = reinterpret_cast<decltype(a->GroupEnd)>(dlsym(a->lib, "ncclGroupEnd"));
+            a->GetErrorString = reinterpret_cast<decltype(a->GetErrorString)>(dlsym(a->lib, "ncclGetErrorString"));
+            return a;
+        }();
+        return api;
+    }
+    bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
+    const char *text(int r) const { return GetErrorString ? GetErrorString(r) : "RCCL error"; }
+};
+
 struct orr_cluster {
     std::vector<orr_index *> shards;
     int32_t dim = 0;
@@ -3084,6 +3118,15 @@ struct orr_cluster {
     std::shared_mutex mu;              // searches share it (they run side by side, each shard search on a lane of its shard); seal / destroy take it alone
     std::mutex stats_mu;
     orr_search_stats sstats{};
+    // optional record exchange over RCCL ("exchange" = 1): one communicator per shard device, one all-gather of the per-shard
+    // [B][k'+1] records on the shards' exchange streams, the merge reads device 0's gathered copy.  One exchange at a time.
+    int exchange = 0;                  // 0: pinned host memory (default); 1: RCCL all-gather over xGMI
+    std::mutex rccl_mu;
+    std::vector<void *> comms;         // [G], created at the first exchange
+    std::vector<hipStream_t> xstreams; // [G]
+    std::vector<DevBuf> xsend, xrecv;  // [G] grow-only
+    PinnedBuf xhost;
+    int64_t rccl_exchanges = 0;        // all-gathers done (orr_cluster_search_stats reports them in reserved[0])
 };
 
 namespace {
@@ -3166,6 +3209,67 @@ int for_each_shard(int32_t n, const std::function<int(int32_t)> &fn)
     return ORR_OK;
 }
 
+// Communicators, exchange streams and buffers of a cluster's RCCL record exchange (caller holds c->rccl_mu).  Any failure
+// switches the cluster back to the pinned-host exchange for good and says why in orr_last_error().
+int rccl_prepare(orr_cluster *c, size_t bytes_per_shard)
+{
+    const int G = (int)c->shards.size();
+    RcclApi *api = RcclApi::get();
+    auto give_up = [&](const char *why, const char *detail) {
+        c->exchange = 0;
+        return fail(ORR_ECOMM, "orr_cluster: RCCL exchange disabled (%s%s%s); records travel through pinned host memory", why, detail ? ": " : "", detail ? detail : "");
+    };
+    if (!api->ok()) return give_up("librccl.so could not be loaded", dlerror());
+    if (c->comms.empty()) {
+        std::vector<int> devs((size_t)G);
+        for (int g = 0; g < G; ++g) {
+            devs[(size_t)g] = c->shards[(size_t)g]->device;
+            for (int h = 0; h < g; ++h)
+                if (devs[(size_t)h] == devs[(size_t)g]) return give_up("two shards share a device, a communicator needs distinct ones", nullptr);
+        }
+        std::vector<void *> comms((size_t)G, nullptr);
+        const int r = api->CommInitAll(comms.data(), G, devs.data());
+        if (r != 0) return give_up("ncclCommInitAll failed", api->text(r));
+        c->comms = comms;
+        c->xstreams.assign((size_t)G, nullptr);
+        c->xsend.resize((size_t)G);
+        c->xrecv.resize((size_t)G);
+        for (int g = 0; g < G; ++g) {
+            if (hipSetDevice(devs[(size_t)g]) != hipSuccess || hipStreamCreateWithFlags(&c->xstreams[(size_t)g], hipStreamNonBlocking) != hipSuccess)
+                return give_up("cannot create an exchange stream", nullptr);
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        if (hipSetDevice(c->shards[(size_t)g]->device) != hipSuccess) return give_up("hipSetDevice failed", nullptr);
+        if (c->xsend[(size_t)g].reserve(bytes_per_shard) != ORR_OK || c->xrecv[(size_t)g].reserve(bytes_per_shard * (size_t)G) != ORR_OK)
+            return give_up("no device memory for the exchange buffers", nullptr);
+    }
+    if (c->xhost.reserve(bytes_per_shard * (size_t)G) != ORR_OK) return give_up("no pinned memory for the gathered records", nullptr);
+    return ORR_OK;
+}
+
+// One all-gather of the shards' records (grouped: one thread drives every device), then device 0's gathered copy -> out.
+int rccl_all_gather(orr_cluster *c, size_t bytes_per_shard, orr_candidate *out)
+{
+    const int G = (int)c->shards.size();
+    RcclApi *api = RcclApi::get();
+    int r = api->GroupStart();
+    for (int g = 0; g < G && r == 0; ++g)
+        r = api->AllGather(c->xsend[(size_t)g].p, c->xrecv[(size_t)g].p, bytes_per_shard, /* ncclInt8 */ 0, c->comms[(size_t)g], c->xstreams[(size_t)g]);
+    const int r2 = api->GroupEnd();
+    if (r == 0) r = r2;
+    if (r != 0) { c->exchange = 0; return fail(ORR_ECOMM, "orr_cluster: ncclAllGather failed: %s", api->text(r)); }
+    HIP_TRY(hipSetDevice(c->shards[0]->device));
+    HIP_TRY(hipMemcpyAsync(c->xhost.p, c->xrecv[0].p, bytes_per_shard * (size_t)G, hipMemcpyDeviceToHost, c->xstreams[0]));
+    for (int g = 0; g < G; ++g) {                       // every device's part of the collective is over before the buffers are reused
+        HIP_TRY(hipSetDevice(c->shards[(size_t)g]->device));
+        HIP_TRY(hipStreamSynchronize(c->xstreams[(size_t)g]));
+    }
+    memcpy(out, c->xhost.p, bytes_per_shard * (size_t)G);
+    c->rccl_exchanges += 1;
+    return ORR_OK;
+}
+
 int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<int32_t> &ids, bool whole, int64_t kprime, int64_t n_total,
                        int64_t *out_rows, double *out_scores, int32_t *out_counts, int depth)
 {
@@ -3199,6 +3303,17 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
     // until this pass has looked at what the screen kept on them
     std::vector<Lane> lanes((size_t)G);
     std::vector<orr_index *> on((size_t)G, nullptr);
+    // "exchange" = 1: the shards write their records into per-device send buffers and ONE RCCL all-gather brings every shard's
+    // records to every device; the merge reads device 0's copy.  (One exchange at a time per cluster: the communicators are
+    // not shared between concurrent collectives.)
+    std::unique_lock<std::mutex> rccl_lock(c->rccl_mu, std::defer_lock);
+    bool via_rccl = false;
+    const size_t rec_bytes_shard = sizeof(orr_candidate) * rec_per_shard;
+    if (c->exchange == 1) {
+        rccl_lock.lock();
+        via_rccl = rccl_prepare(c, rec_bytes_shard) == ORR_OK;
+        if (!via_rccl) rccl_lock.unlock();
+    }
     ORR_TRY(for_each_shard(G, [&](int32_t g) -> int {
         ORR_TRY(lanes[(size_t)g].acquire(c->shards[(size_t)g]));
         orr_index *sh = lanes[(size_t)g].lane;
@@ -3207,12 +3322,21 @@ int cluster_search_ids(orr_cluster *c, const BatchArgs &orig, const std::vector<
         BatchArgs mine = cur;
         const float *qh = nullptr;
         const orr_candidate *recs = nullptr;
-        ORR_TRY(run_shard(sh, mine, (int32_t)kprime, true, &qh, &recs));
-        if (recs) memcpy(all.data() + (size_t)g * rec_per_shard, recs, sizeof(orr_candidate) * rec_per_shard);
-        else HIP_TRY(hipMemcpy(all.data() + (size_t)g * rec_per_shard, sh->ws_cand.p, sizeof(orr_candidate) * rec_per_shard, hipMemcpyDeviceToHost));
+        if (via_rccl) {
+            mine.out_dev = c->xsend[(size_t)g].as<orr_candidate>();          // complete when run_shard returns (it synchronises its stream)
+            ORR_TRY(run_shard(sh, mine, (int32_t)kprime, false, &qh, &recs));
+        } else {
+            ORR_TRY(run_shard(sh, mine, (int32_t)kprime, true, &qh, &recs));
+            if (recs) memcpy(all.data() + (size_t)g * rec_per_shard, recs, sizeof(orr_candidate) * rec_per_shard);
+            else HIP_TRY(hipMemcpy(all.data() + (size_t)g * rec_per_shard, sh->ws_cand.p, sizeof(orr_candidate) * rec_per_shard, hipMemcpyDeviceToHost));
+        }
         used_two_stage[(size_t)g] = mine.used_two_stage; used_fused[(size_t)g] = mine.used_fused; used_mfma[(size_t)g] = mine.used_mfma;
         return ORR_OK;
     }));
+    if (via_rccl) {
+        ORR_TRY(rccl_all_gather(c, rec_bytes_shard, all.data()));
+        rccl_lock.unlock();
+    }
     std::unique_lock<std::mutex> stats_lock(c->stats_mu);
     c->sstats.passes += 1;
     c->sstats.pass_mode = on[0]->sstats.pass_mode;
@@ -3327,8 +3451,40 @@ int orr_cluster_create(const int32_t *devices, int32_t n_shards, int32_t dim, in
 void orr_cluster_destroy(orr_cluster *c)
 {
     if (!c) return;
+    if (!c->comms.empty()) {
+        RcclApi *api = RcclApi::get();
+        for (size_t g = 0; g < c->comms.size(); ++g) {
+            if (g < c->shards.size()) (void)hipSetDevice(c->shards[g]->device);
+            if (g < c->xstreams.size() && c->xstreams[g]) { (void)hipStreamSynchronize(c->xstreams[g]); (void)hipStreamDestroy(c->xstreams[g]); }
+            if (c->comms[g] && api->CommDestroy) (void)api->CommDestroy(c->comms[g]);
+            if (g < c->xsend.size()) c->xsend[g].release();
+            if (g < c->xrecv.size()) c->xrecv[g].release();
+        }
+    }
+    c->xhost.release();
     for (orr_index *sh : c->shards) orr_index_destroy(sh);
     delete c;
+}
+
+int orr_cluster_set_option(orr_cluster *c, const char *name, int64_t value)
+{
+    if (!c || !name) return fail(ORR_EINVAL, "orr_cluster_set_option: null argument");
+    std::unique_lock<std::shared_mutex> lock(c->mu);
+    if (strcmp(name, "exchange") == 0) {
+        if (value != 0 && value != 1) return fail(ORR_EINVAL, "orr_cluster_set_option: exchange takes 0 (pinned host memory) or 1 (RCCL all-gather)");
+        if (value == 1) {
+            if (!RcclApi::get()->ok()) return fail(ORR_ECOMM, "orr_cluster_set_option: librccl.so could not be loaded");
+            for (size_t g = 0; g < c->shards.size(); ++g)
+                for (size_t h = 0; h < g; ++h)
+                    if (c->shards[h]->device == c->shards[g]->device)
+                        return fail(ORR_EINVAL, "orr_cluster_set_option: the RCCL exchange needs every shard on a device of its own (shards %zu and %zu share device %d)",
+                                    h, g, c->shards[g]->device);
+        }
+        std::lock_guard<std::mutex> l(c->rccl_mu);
+        c->exchange = (int)value;
+        return ORR_OK;
+    }
+    return fail(ORR_EINVAL, "orr_cluster_set_option: unknown option %s", name);
 }
 
 int32_t orr_cluster_shards(const orr_cluster *c) { return c ? (int32_t)c->shards.size() : 0; }
@@ -3441,7 +3597,7 @@ int orr_cluster_search_stats(orr_cluster *c, orr_search_stats *out, int32_t rese
 {
     if (!c) return fail(ORR_EINVAL, "orr_cluster_search_stats: null cluster");
     std::lock_guard<std::mutex> lock(c->stats_mu);
-    if (out) *out = c->sstats;
+    if (out) { *out = c->sstats; out->reserved[0] = c->rccl_exchanges; }
     if (reset) c->sstats = orr_search_stats{};
     return ORR_OK;
 }

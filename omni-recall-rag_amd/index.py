@@ -324,6 +324,10 @@ class RecallCluster:
                                                int(candidate_limit), _ptr(rows), _ptr(scores), _ptr(counts)))
         return rows, scores, counts
 
+    def set_option(self, name: str, value: int) -> None:
+        """orr_cluster_set_option ("exchange": 0 pinned host memory, 1 RCCL all-gather)."""
+        N.check(N.hip.orr_cluster_set_option(self._h, name.encode(), int(value)))
+
     def compact(self) -> int:
         """orr_cluster_compact: every shard without its deleted rows, placed in the global order again."""
         done = C.c_int64(0)
@@ -335,6 +339,7 @@ class RecallCluster:
         N.check(N.hip.orr_cluster_search_stats(self._h, C.byref(st), 1 if reset else 0))
         d = {n: int(getattr(st, n)) for n, _ in N.OrrSearchStats._fields_ if n != "reserved"}
         d["survivors_per_query"] = d["survivors_total"] / d["survivor_samples"] if d["survivor_samples"] else None
+        d["rccl_exchanges"] = int(st.reserved[0])
         return d
 
 

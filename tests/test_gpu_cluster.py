@@ -184,3 +184,42 @@ def test_cluster_compaction_moves_the_later_shards_up():
             orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=limit)
             assert list(rows[b, :counts[b]]) == [keep[int(r)] for r in orow] and np.array_equal(scores[b, :counts[b]], osc), (topk, limit, b)
     cl.close()
+
+
+def test_cluster_record_exchange_over_rccl():
+    """"exchange" = 1: the shards' records travel by ONE ncclAllGather (RCCL, bound at run time) instead of through pinned host
+    memory.  A communicator needs distinct devices, so on a one-GPU box only the one-shard cluster can run it (an all-gather of
+    one rank: the whole path -- dlopen, communicator, grouped call on the exchange stream, device 0's copy to the host, merge --
+    is the same); two shards on one card are refused, and the pinned-host path keeps working afterwards."""
+    P = pkg()
+    rng = np.random.default_rng(71)
+    n, dim = 1800, 32
+    c = _sorted_corpus(rng, n, dim)
+    corpus = orc.OracleCorpus(c["emb"], c["created"], c["contents"])
+    qs = rng.standard_normal((7, dim)).astype(np.float32)
+    texts = [QUERY_TEXTS[b % len(QUERY_TEXTS)] for b in range(7)]
+    terms = [P.text.query_terms(t) for t in texts]
+    one = P.RecallCluster([0], dim)
+    _fill(P, one, c, [0, n])
+    one.set_option("exchange", 1)
+    for topk, limit in ((10, n), (3, 300), (70, n)):                     # (70: the large-k path; k' grows)
+        rows, scores, counts = one.search(qs, terms, NOW, topk, candidate_limit=limit)
+        for b in range(7):
+            orow, osc, _ = corpus.search(qs[b], texts[b], NOW, topk, candidate_limit=limit)
+            assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (topk, limit, b)
+    st = one.search_stats()
+    assert st["rccl_exchanges"] >= 3, st
+    one.set_option("exchange", 0)
+    before = st["rccl_exchanges"]
+    one.search(qs, terms, NOW, 5, candidate_limit=n)
+    assert one.search_stats()["rccl_exchanges"] == before
+    one.close()
+    two = P.RecallCluster([0, 0], dim)
+    _fill(P, two, c, [0, 900, n])
+    with pytest.raises(P.OrrError):
+        two.set_option("exchange", 1)                                    # two shards on one device: no communicator
+    rows, scores, counts = two.search(qs, terms, NOW, 5, candidate_limit=n)
+    for b in range(7):
+        orow, osc, _ = corpus.search(qs[b], texts[b], NOW, 5, candidate_limit=n)
+        assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), b
+    two.close()
