@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     ap.add_argument("--cpu-sample-queries", type=int, default=32)
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of the headline shape, FETCH_SIZE and "
+                         "WRITE_SIZE, before this process touches the GPU); the committed figure of the same shape is quoted instead")
     ap.add_argument("--no-legs", action="store_true", help="headline only: skip the C2 leg (one GPU) / the C4 legs (several)")
     ap.add_argument("--no-overlap-leg", action="store_true", help="skip the two-steps-in-flight measurements (headline and C2 leg: reported beside `value`, never as it)")
     ap.add_argument("--no-robustness-legs", action="store_true",
@@ -144,6 +147,68 @@ def cgroup_cpu_quota():
         return None if quota <= 0 else round(quota / period, 2)
     except Exception:
         return None
+
+
+PMC_KERNEL_SYMBOLS = {"screen_i8_fused": ("screen_tile16_kernel", "screen_tile4_kernel", "screen_bf16_kernel<true, true"),
+                      "screen_gemv_i8": ("screen_gemv_i8_kernel",), "screen_gemv_bf16": ("screen_gemv_bf16_kernel",),
+                      "screen_bf16_fused": ("screen_bf16_kernel<true, false",), "dot_exact": ("dot_exact_tiled",)}
+
+
+def measure_traffic(args):
+    """roofline.traffic measured IN THIS RUN: HBM bytes per launch of the headline's kernels from the PMC counters, collected as
+    MI355X_MICROARCH.md (HBM / rocprofv3) prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one), with
+    --kernel-trace only; both counters read in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced stream, so
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE.  Two child runs of the headline shape (3 steps each) BEFORE this process touches the GPU.
+    Returns {kernel name: {bytes_per_launch, launches, ...}} or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.abspath(__file__),
+             "--gpus", "1", "--no-legs", "--no-overlap-leg", "--no-cpu-baseline", "--no-pmc", "--steps", "3", "--warmup", "2",
+             "--dim", str(args.dim), "--topk", str(args.topk), "--rows-per-gpu", str(args.rows_per_gpu), "--batch", str(args.batch)]
+    for o in args.set_option:
+        child += ["--set-option", o]
+    if args.no_terms:
+        child.append("--no-terms")
+    out, t0 = {}, time.perf_counter()
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="orr_pmc_")
+        try:
+            cmd = [rocprof, "--output-format", "csv", "--kernel-trace", "--pmc", counter, "-d", tmp, "--"] + child
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, env=env, cwd="/tmp")
+            files = glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %d csv file(s): %s" % (counter, p.returncode, len(files), p.stderr.decode(errors="replace")[-160:])}
+            for f in files:
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") != counter:
+                            continue
+                        for name, symbols in PMC_KERNEL_SYMBOLS.items():
+                            if any(sym in r["Kernel_Name"] for sym in symbols):
+                                e = sums.setdefault(name, {}).setdefault(counter, [0.0, 0])
+                                e[0] += float(r["Counter_Value"])
+                                e[1] += 1
+        except Exception as exc:                       # a timeout, a refused profiler: the committed figure is quoted instead
+            return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:160])}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    for name, cs in sums.items():
+        if "FETCH_SIZE" in cs and cs["FETCH_SIZE"][1]:
+            fetch = cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1] * 1024.0
+            write = (cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1] * 1024.0) if cs.get("WRITE_SIZE", [0, 0])[1] else 0.0
+            out[name] = {"hbm_bytes_per_launch": 2.0 * fetch + write, "fetch_size_bytes_avg": fetch, "write_size_bytes_avg": write,
+                         "launches_seen": cs["FETCH_SIZE"][1]}
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    out["how"] = ("this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of the headline shape, 3 steps), "
+                  "bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch, counters in KiB (MI355X_MICROARCH.md, HBM)")
+    return out
 
 
 def spawn_ranks(args, argv):
@@ -330,6 +395,17 @@ def _committed_traffic(kernel, rows, dim, B):
     return None, None, 1
 
 
+MEASURED_TRAFFIC = {}        # kernel name -> measure_traffic()'s entry, set by run() for the headline leg only
+
+
+def _traffic(kernel, rows, dim, B):
+    """HBM bytes per launch: measured in this run where that was done (the headline), else this round's committed PMC passes."""
+    m = MEASURED_TRAFFIC.get(kernel)
+    if m:
+        return m["hbm_bytes_per_launch"], MEASURED_TRAFFIC.get("how"), None
+    return _committed_traffic(kernel, rows, dim, B)
+
+
 def roofline_of(stats, rows, dim, B, steps):
     """The dominant kernel of the leg against its roofline.  `achieved` is priced on the bytes / operations the kernel
     really performs (it streams the int8 shadow: N*D bytes); `frac_survey_8d` prices the same launch on SURVEY.md
@@ -343,7 +419,7 @@ def roofline_of(stats, rows, dim, B, steps):
         if a:
             ms, bytes_per_launch = a
             achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-            traffic, src, _ = _committed_traffic(name, rows, dim, B)
+            traffic, src, _ = _traffic(name, rows, dim, B)
             return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": ms,
                     "algo_bytes_per_launch": bytes_per_launch,
@@ -363,8 +439,8 @@ def roofline_of(stats, rows, dim, B, steps):
             crossover = I8_CROSSOVER_B if i8 else I8_CROSSOVER_B / 2.0 * (MFMA_BF16_PEAK_TFLOPS / MFMA_I8_PEAK_TOPS) * 2.0
             gbs = bytes_per_launch / (ms * 1e-3) / 1e9
             tops = ops / (ms * 1e-3) / 1e12
-            traffic, src, committed_per_step = _committed_traffic(name, rows, dim, B)
-            if traffic is not None:
+            traffic, src, committed_per_step = _traffic(name, rows, dim, B)
+            if traffic is not None and committed_per_step:
                 traffic *= committed_per_step / per_step          # (the committed figure is per launch of ITS run)
             hbm_bound = B < crossover
             r = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
@@ -565,6 +641,8 @@ def compact_line(out, full_path=None):
                                    "algo_bytes_per_launch", "frac_survey_8d"), 5)
         if "mfma" in rf:
             c["roofline"]["mfma_frac"] = _r(rf["mfma"].get("frac"))
+        if "traffic_measured_in_this_run" in rf:
+            c["roofline"]["traffic_in_run"] = rf["traffic_measured_in_this_run"]
         if "step_hbm_frac" in rf:
             c["roofline"]["step_hbm_frac"] = _r(rf["step_hbm_frac"])
     else:
@@ -633,12 +711,17 @@ def main():
     launched = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and args.mode == "ranks" and not launched:
         spawn_ranks(args, argv)                    # never returns
-    cluster_mode = args.gpus > 1 and args.mode == "cluster"
+    cluster_mode = args.mode == "cluster"          # (one device too: a one-shard cluster, e.g. to rehearse the RCCL exchange on a one-GPU box)
     world = 1 if cluster_mode else int(os.environ.get("WORLD_SIZE", "1"))
     rank = 0 if cluster_mode else int(os.environ.get("RANK", "0"))
     if not cluster_mode and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     probe = host_probe() if rank == 0 else {}      # child processes only; before the first GPU call of this process
+    if rank == 0 and world == 1 and not cluster_mode and not args.no_pmc:
+        try:
+            probe["pmc"] = measure_traffic(args)       # (children too: the profiler must not meet a process that already holds the GPU)
+        except Exception as exc:
+            probe["pmc"] = {"error": repr(exc)[:200]}
     state = {"t_start": time.perf_counter(), "out": None, "dist": None}
     try:
         run(args, probe, state, cluster_mode, world, rank)
@@ -756,7 +839,15 @@ def run(args, probe, state, cluster_mode, world, rank):
         idx = build_shard(P, syn, torch, 0, rows, dim, rows, dev, args.set_option)
         setup_s["headline_corpus"] = time.perf_counter() - t0
         head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, 1), rows, rows, B, terms=not args.no_terms)
+        pmc = probe.get("pmc") or {}
+        if "error" not in pmc:
+            MEASURED_TRAFFIC.update(pmc)                # (the children ran the headline's shape: only this leg may quote them)
         head = run_leg(head_leg, args, env, idx, None, syn, overlap=not args.no_overlap_leg)
+        MEASURED_TRAFFIC.clear()
+        if head.get("roofline") is not None:
+            head["roofline"]["traffic_measured_in_this_run"] = bool(pmc) and "error" not in pmc and head["roofline"].get("traffic") is not None
+            if pmc.get("error"):
+                head["roofline"]["traffic_pmc_error"] = pmc["error"]
         n_total, front = rows, None
     else:
         rows = args.rows_per_gpu or 12_500_000
