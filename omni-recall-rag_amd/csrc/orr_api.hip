@@ -1779,6 +1779,204 @@ struct HostTiming {
 };
 thread_local HostTiming g_ht;          // per searching thread: lanes (views) and cluster workers each time their own calls
 
+// ---- K3, the keyword side of one pass, on its own stream (with the int8 prefix the main stream has little to do before it
+// needs the bitmaps, so this chain is the critical path of a batch): distinct terms -> vocabulary scan -> (term, token) hits ->
+// per distinct term a row bitmap: a stored token bitmap where the term's only hit has one (ensure_token_bitmaps), else its
+// posting lists OR-ed into the batch's own bitmaps (orr_token_index.cpp: why this equals RecallSearchService.cs:111).
+struct KwSide {
+    orr::KwView view{nullptr, 0, nullptr, nullptr, nullptr};
+    size_t bm_bytes = 0, bm_clean_before = 0;     // the batch's own bitmaps: bytes used, bytes known to be zero on entry
+    bool overflow_possible = false;               // the hit list may have been too short (checked behind the pass)
+    uint32_t max_hits = 0;
+};
+
+int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<uint32_t> &qoff, KwSide &out)
+{
+    const int32_t B = a.B;
+    const uint32_t t_begin = qoff[0], n_terms_total = qoff[(size_t)B] - qoff[0];
+    if (n_terms_total == 0) return ORR_OK;
+    {
+
+        // distinct terms of the batch: open addressing on an FNV-1a hash of the bytes (a batch of 1024 queries has
+        // ~3000 terms; the node-based map this replaces cost as much as the GPU side of a small batch)
+        std::vector<std::string_view> dterms;
+        dterms.reserve(n_terms_total);
+        uint32_t table_size = 16;
+        while (table_size < 2 * n_terms_total + 2) table_size <<= 1;
+        std::vector<uint32_t> table(table_size, 0xFFFFFFFFu);
+        std::vector<uint32_t> qmeta((size_t)n_terms_total + (size_t)B + 1);   // [term -> distinct idx][query offsets]
+        for (uint32_t t = 0; t < n_terms_total; ++t) {
+            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
+            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
+            std::string_view sv(reinterpret_cast<const char *>(a.terms_utf8) + o, e - o);
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char ch : sv) h = (h ^ ch) * 1099511628211ull;
+            uint32_t slot = (uint32_t)(h ^ (h >> 32)) & (table_size - 1);
+            while (table[slot] != 0xFFFFFFFFu && dterms[table[slot]] != sv) slot = (slot + 1) & (table_size - 1);
+            if (table[slot] == 0xFFFFFFFFu) {
+                table[slot] = (uint32_t)dterms.size();
+                dterms.push_back(sv);
+            }
+            qmeta[t] = table[slot];
+        }
+        for (int32_t b = 0; b <= B; ++b) qmeta[n_terms_total + b] = qoff[b] - t_begin;
+        const uint32_t TT = (uint32_t)dterms.size();
+        size_t pool_bytes = 0;
+        for (auto &d : dterms) pool_bytes += d.size();
+        // one pinned block, one upload: [ScanTerm x TT][qmeta][iota 0..64][term bytes]
+        const size_t off_terms = 0;
+        const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
+        const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
+        const size_t off_match = off_iota + sizeof(uint32_t) * 65;
+        const size_t off_pool = off_match + sizeof(orr::MatchTerm) * TT;
+        const size_t meta_bytes = off_pool + pool_bytes + 16;
+        ORR_TRY(idx->pin_meta.reserve(meta_bytes));
+        ORR_TRY(idx->ws_meta.reserve(meta_bytes));
+        uint8_t *hm = idx->pin_meta.as<uint8_t>();
+        orr::ScanTerm *st = reinterpret_cast<orr::ScanTerm *>(hm + off_terms);
+        uint32_t cursor = 0;
+        for (uint32_t t = 0; t < TT; ++t) {
+            st[t].off = cursor;
+            st[t].len = (uint32_t)dterms[t].size();
+            uint32_t pre = 0, msk = 0;
+            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
+                pre |= (uint32_t)(uint8_t)dterms[t][k] << (8 * k);
+                msk |= 0xFFu << (8 * k);
+            }
+            st[t].prefix = pre;
+            st[t].mask = msk;
+            orr::MatchTerm &mt = reinterpret_cast<orr::MatchTerm *>(hm + off_match)[t];
+            memset(&mt, 0, sizeof(mt));
+            mt.len = st[t].len;
+            for (uint32_t k = 0; k < 16 && k < st[t].len; ++k) {
+                mt.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
+                mt.m[k >> 2] |= 0xFFu << (8 * (k & 3));
+            }
+            memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
+            cursor += st[t].len;
+        }
+        memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
+        uint32_t *iota = reinterpret_cast<uint32_t *>(hm + off_iota);
+        for (uint32_t i = 0; i < 65; ++i) iota[i] = i;
+
+        const int64_t V = idx->n_tokens;
+        const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
+        const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
+        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, idx->kw_hits_cap);
+        ORR_TRY(ensure_vlong(idx));
+        ORR_TRY(ensure_token_bitmaps(idx));
+        const int64_t VL = idx->n_vlong;
+        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
+        ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
+        // The term bitmaps must start out zero.  Every search clears what it used again when it is done (on this side
+        // stream, behind its last kernel, while the host finishes the batch), so the next one only clears what lies
+        // beyond: the memset (270 MB at 1024 queries x 1M rows) leaves the critical path of the keyword chain.
+        out.bm_bytes = sizeof(uint32_t) * (size_t)TT * (size_t)words;
+        size_t bm_clean = idx->bitmaps_clean_of == idx->ws_bitmaps.p ? idx->bitmaps_clean : 0;
+        idx->bitmaps_clean = 0;                        // until this search has cleaned up after itself
+        idx->bitmaps_clean_of = idx->ws_bitmaps.p;
+        out.bm_clean_before = bm_clean;
+        ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
+        ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
+        ORR_TRY(idx->pin_kwcnt.reserve(sizeof(unsigned long long)));
+        *idx->pin_kwcnt.as<unsigned long long>() = 0ull;
+        hipStream_t k = idx->stream_kw;
+        uint8_t *dm = idx->ws_meta.as<uint8_t>();
+        HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
+        if (bm_clean < out.bm_bytes)
+            HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(idx->ws_bitmaps.p) + bm_clean, 0, out.bm_bytes - bm_clean, k));
+        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
+        if (V > 0) {
+            const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
+            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
+                Timed t(idx, "vocab_match", 0.0, k);
+                HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
+                                                      reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
+                                                      idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+            }
+            if (VL > 0) {   // longer tokens: every distinct term is its own 1-term "query" of the wave-per-token scan
+                {
+                    Timed t(idx, "vocab_scan", 0.0, k);
+                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(), VL,
+                                                   dm + off_pool, d_terms, (int32_t)TT, reinterpret_cast<const uint32_t *>(dm + off_iota),
+                                                   idx->ws_vmatch.as<uint16_t>(), k));
+                }
+                {
+                    Timed t(idx, "vocab_hits", 0.0, k);
+                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VL, (int32_t)TT, idx->vlong_id.as<uint32_t>(), idx->d_post_off,
+                                                   idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+                }
+            }
+            // terms whose only hit is a token with a stored bitmap use that bitmap as it is (no expansion, nothing copied)
+            const uint8_t *skip = nullptr;
+            if (idx->n_tok_bm > 0 && idx->tok_bm_words == words) {
+                const size_t o_tok = sizeof(uint32_t) * (size_t)TT, o_off = (2 * o_tok + 7) / 8 * 8, o_alias = o_off + sizeof(int64_t) * (size_t)TT;
+                ORR_TRY(idx->ws_kwalias.reserve(o_alias + (size_t)TT + 16));
+                uint8_t *wa = idx->ws_kwalias.as<uint8_t>();
+                HIP_TRY(hipMemsetAsync(wa, 0, o_tok, k));                  // the hit counts
+                const int64_t delta = (int64_t)(idx->tok_bm.as<uint32_t>() - idx->ws_bitmaps.as<uint32_t>());   // words from the batch's bitmaps to the token store
+                Timed t(idx, "kw_alias", 0.0, k);
+                HIP_TRY(orr::launch_kw_alias(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits, (int32_t)TT,
+                                             idx->tok_bm_index.as<int32_t>(), delta, words, reinterpret_cast<uint32_t *>(wa),
+                                             reinterpret_cast<uint32_t *>(wa + o_tok), reinterpret_cast<int64_t *>(wa + o_off), wa + o_alias, k));
+                out.view.term_word_off = reinterpret_cast<const int64_t *>(wa + o_off);
+                skip = wa + o_alias;
+            }
+            {
+                Timed t(idx, "expand_hits", 0.0, k);
+                HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
+                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k,
+                                                idx->pin_kwcnt.as<unsigned long long>(), skip));     // hits of this pass: statistics
+            }
+        }
+        HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
+        out.view.bitmaps = idx->ws_bitmaps.as<uint32_t>();
+        out.view.words_per_term = words;
+        out.view.q_term_idx = reinterpret_cast<const uint32_t *>(dm + off_qmeta);
+        out.view.q_term_off = out.view.q_term_idx + n_terms_total;
+        out.overflow_possible = want_hits > (uint64_t)max_hits;
+        out.max_hits = max_hits;
+    }
+    return ORR_OK;
+}
+
+// Generic path for large k (topK beyond the 64 entries a wave keeps): every score of a query, a stable descending radix sort
+// (hipCUB), the first k' rows as records -- query by query.
+int run_large_k(orr_index *idx, const BatchArgs &a, int32_t kprime, int64_t n, const double *d_dot, const orr::KwView &kw,
+                const orr::QueryConst *qc, orr_candidate *d_cand, hipStream_t s)
+{
+    const int32_t B = a.B;
+    // generic large-k path: full stable sort of every score, query by query
+    ORR_TRY(idx->ws_keys_a.reserve(sizeof(unsigned long long) * (size_t)n));
+    ORR_TRY(idx->ws_keys_b.reserve(sizeof(unsigned long long) * (size_t)n));
+    ORR_TRY(idx->ws_vals_a.reserve(sizeof(uint32_t) * (size_t)n));
+    ORR_TRY(idx->ws_vals_b.reserve(sizeof(uint32_t) * (size_t)n));
+    size_t tmp_bytes = 0;
+    HIP_TRY(orr::sort_pairs_desc(nullptr, tmp_bytes, idx->ws_keys_a.as<unsigned long long>(),
+                                 idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(),
+                                 idx->ws_vals_b.as<uint32_t>(), n, s));
+    ORR_TRY(idx->ws_sort_tmp.reserve(tmp_bytes));
+    for (int32_t b = 0; b < B; ++b) {
+        const double *dq = d_dot ? d_dot + (size_t)b * n : nullptr;
+        {
+            Timed t(idx, "score_keys", (double)n * 36.0);
+            HIP_TRY(orr::launch_score_keys(dq, idx->d_norm_b, idx->d_created, kw, b, qc[b], a.now_ticks, n,
+                                           idx->ws_keys_a.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(), s));
+        }
+        {
+            Timed t(idx, "radix_sort_desc", (double)n * 12.0 * 2.0 * 8.0);
+            size_t tb = idx->ws_sort_tmp.cap;
+            HIP_TRY(orr::sort_pairs_desc(idx->ws_sort_tmp.p, tb, idx->ws_keys_a.as<unsigned long long>(),
+                                         idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(),
+                                         idx->ws_vals_b.as<uint32_t>(), n, s));
+        }
+        HIP_TRY(orr::launch_records_from_sorted(idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_b.as<uint32_t>(),
+                                                kprime, n, idx->row_base, d_dot, n, idx->d_norm_b, idx->d_created,
+                                                idx->d_row_ids, kw, b, 1, d_cand + (size_t)b * (kprime + 1), s));
+    }
+    return ORR_OK;
+}
+
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
@@ -1912,154 +2110,13 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
         return ORR_OK;
     }
 
-    // ---- K3 keyword side first, on its own stream (with the int8 prefix the main stream has little to do before it
-    // needs the bitmaps, so this chain is the critical path of a batch): distinct terms -> vocabulary scan -> posting lists
-    // OR-ed into one row bitmap per distinct term (orr_token_index.cpp: why this equals :111)
-    orr::KwView kw{nullptr, 0, nullptr, nullptr, nullptr};
-    size_t bm_bytes = 0, bm_clean_before = 0;
-    bool kw_overflow_possible = false;
-    uint32_t kw_max_hits = 0;
-    if (n_terms_total > 0) {
-        // distinct terms of the batch: open addressing on an FNV-1a hash of the bytes (a batch of 1024 queries has
-        // ~3000 terms; the node-based map this replaces cost as much as the GPU side of a small batch)
-        std::vector<std::string_view> dterms;
-        dterms.reserve(n_terms_total);
-        uint32_t table_size = 16;
-        while (table_size < 2 * n_terms_total + 2) table_size <<= 1;
-        std::vector<uint32_t> table(table_size, 0xFFFFFFFFu);
-        std::vector<uint32_t> qmeta((size_t)n_terms_total + (size_t)B + 1);   // [term -> distinct idx][query offsets]
-        for (uint32_t t = 0; t < n_terms_total; ++t) {
-            const uint32_t o = a.term_off[t_begin + t], e = a.term_off[t_begin + t + 1];
-            if (e < o) return fail(ORR_EINVAL, "term_off is not monotone at term %u", t_begin + t);
-            std::string_view sv(reinterpret_cast<const char *>(a.terms_utf8) + o, e - o);
-            uint64_t h = 1469598103934665603ull;
-            for (unsigned char ch : sv) h = (h ^ ch) * 1099511628211ull;
-            uint32_t slot = (uint32_t)(h ^ (h >> 32)) & (table_size - 1);
-            while (table[slot] != 0xFFFFFFFFu && dterms[table[slot]] != sv) slot = (slot + 1) & (table_size - 1);
-            if (table[slot] == 0xFFFFFFFFu) {
-                table[slot] = (uint32_t)dterms.size();
-                dterms.push_back(sv);
-            }
-            qmeta[t] = table[slot];
-        }
-        for (int32_t b = 0; b <= B; ++b) qmeta[n_terms_total + b] = qoff[b] - t_begin;
-        const uint32_t TT = (uint32_t)dterms.size();
-        size_t pool_bytes = 0;
-        for (auto &d : dterms) pool_bytes += d.size();
-        // one pinned block, one upload: [ScanTerm x TT][qmeta][iota 0..64][term bytes]
-        const size_t off_terms = 0;
-        const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
-        const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
-        const size_t off_match = off_iota + sizeof(uint32_t) * 65;
-        const size_t off_pool = off_match + sizeof(orr::MatchTerm) * TT;
-        const size_t meta_bytes = off_pool + pool_bytes + 16;
-        ORR_TRY(idx->pin_meta.reserve(meta_bytes));
-        ORR_TRY(idx->ws_meta.reserve(meta_bytes));
-        uint8_t *hm = idx->pin_meta.as<uint8_t>();
-        orr::ScanTerm *st = reinterpret_cast<orr::ScanTerm *>(hm + off_terms);
-        uint32_t cursor = 0;
-        for (uint32_t t = 0; t < TT; ++t) {
-            st[t].off = cursor;
-            st[t].len = (uint32_t)dterms[t].size();
-            uint32_t pre = 0, msk = 0;
-            for (uint32_t k = 0; k < 4 && k < st[t].len; ++k) {
-                pre |= (uint32_t)(uint8_t)dterms[t][k] << (8 * k);
-                msk |= 0xFFu << (8 * k);
-            }
-            st[t].prefix = pre;
-            st[t].mask = msk;
-            orr::MatchTerm &mt = reinterpret_cast<orr::MatchTerm *>(hm + off_match)[t];
-            memset(&mt, 0, sizeof(mt));
-            mt.len = st[t].len;
-            for (uint32_t k = 0; k < 16 && k < st[t].len; ++k) {
-                mt.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
-                mt.m[k >> 2] |= 0xFFu << (8 * (k & 3));
-            }
-            memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
-            cursor += st[t].len;
-        }
-        memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
-        uint32_t *iota = reinterpret_cast<uint32_t *>(hm + off_iota);
-        for (uint32_t i = 0; i < 65; ++i) iota[i] = i;
-
-        const int64_t V = idx->n_tokens;
-        const int64_t words = ((idx->n_rows + 31) / 32 + 3) / 4 * 4;       // 16-byte aligned bitmaps
-        const uint64_t want_hits = (uint64_t)std::max<int64_t>(V, 1) * TT;
-        const uint32_t max_hits = (uint32_t)std::min<uint64_t>(want_hits, idx->kw_hits_cap);
-        ORR_TRY(ensure_vlong(idx));
-        ORR_TRY(ensure_token_bitmaps(idx));
-        const int64_t VL = idx->n_vlong;
-        ORR_TRY(idx->ws_vmatch.reserve(sizeof(uint16_t) * (size_t)TT * (size_t)std::max<int64_t>(VL, 1)));
-        ORR_TRY(idx->ws_bitmaps.reserve(sizeof(uint32_t) * (size_t)TT * (size_t)words));
-        // The term bitmaps must start out zero.  Every search clears what it used again when it is done (on this side
-        // stream, behind its last kernel, while the host finishes the batch), so the next one only clears what lies
-        // beyond: the memset (270 MB at 1024 queries x 1M rows) leaves the critical path of the keyword chain.
-        bm_bytes = sizeof(uint32_t) * (size_t)TT * (size_t)words;
-        size_t bm_clean = idx->bitmaps_clean_of == idx->ws_bitmaps.p ? idx->bitmaps_clean : 0;
-        idx->bitmaps_clean = 0;                        // until this search has cleaned up after itself
-        idx->bitmaps_clean_of = idx->ws_bitmaps.p;
-        bm_clean_before = bm_clean;
-        ORR_TRY(idx->ws_hits.reserve(sizeof(orr::KwHit) * (size_t)max_hits));
-        ORR_TRY(idx->ws_counter.reserve(sizeof(unsigned long long)));
-        ORR_TRY(idx->pin_kwcnt.reserve(sizeof(unsigned long long)));
-        *idx->pin_kwcnt.as<unsigned long long>() = 0ull;
-        hipStream_t k = idx->stream_kw;
-        uint8_t *dm = idx->ws_meta.as<uint8_t>();
-        HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
-        if (bm_clean < bm_bytes)
-            HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(idx->ws_bitmaps.p) + bm_clean, 0, bm_bytes - bm_clean, k));
-        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
-        if (V > 0) {
-            const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
-            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
-                Timed t(idx, "vocab_match", 0.0, k);
-                HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
-                                                      reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
-                                                      idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
-            }
-            if (VL > 0) {   // longer tokens: every distinct term is its own 1-term "query" of the wave-per-token scan
-                {
-                    Timed t(idx, "vocab_scan", 0.0, k);
-                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(), VL,
-                                                   dm + off_pool, d_terms, (int32_t)TT, reinterpret_cast<const uint32_t *>(dm + off_iota),
-                                                   idx->ws_vmatch.as<uint16_t>(), k));
-                }
-                {
-                    Timed t(idx, "vocab_hits", 0.0, k);
-                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VL, (int32_t)TT, idx->vlong_id.as<uint32_t>(), idx->d_post_off,
-                                                   idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
-                }
-            }
-            // terms whose only hit is a token with a stored bitmap use that bitmap as it is (no expansion, nothing copied)
-            const uint8_t *skip = nullptr;
-            if (idx->n_tok_bm > 0 && idx->tok_bm_words == words) {
-                const size_t o_tok = sizeof(uint32_t) * (size_t)TT, o_off = (2 * o_tok + 7) / 8 * 8, o_alias = o_off + sizeof(int64_t) * (size_t)TT;
-                ORR_TRY(idx->ws_kwalias.reserve(o_alias + (size_t)TT + 16));
-                uint8_t *wa = idx->ws_kwalias.as<uint8_t>();
-                HIP_TRY(hipMemsetAsync(wa, 0, o_tok, k));                  // the hit counts
-                const int64_t delta = (int64_t)(idx->tok_bm.as<uint32_t>() - idx->ws_bitmaps.as<uint32_t>());   // words from the batch's bitmaps to the token store
-                Timed t(idx, "kw_alias", 0.0, k);
-                HIP_TRY(orr::launch_kw_alias(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits, (int32_t)TT,
-                                             idx->tok_bm_index.as<int32_t>(), delta, words, reinterpret_cast<uint32_t *>(wa),
-                                             reinterpret_cast<uint32_t *>(wa + o_tok), reinterpret_cast<int64_t *>(wa + o_off), wa + o_alias, k));
-                kw.term_word_off = reinterpret_cast<const int64_t *>(wa + o_off);
-                skip = wa + o_alias;
-            }
-            {
-                Timed t(idx, "expand_hits", 0.0, k);
-                HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
-                                                idx->d_post_rows, idx->ws_bitmaps.as<uint32_t>(), words, k,
-                                                idx->pin_kwcnt.as<unsigned long long>(), skip));     // hits of this pass: statistics
-            }
-        }
-        HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
-        kw.bitmaps = idx->ws_bitmaps.as<uint32_t>();
-        kw.words_per_term = words;
-        kw.q_term_idx = reinterpret_cast<const uint32_t *>(dm + off_qmeta);
-        kw.q_term_off = kw.q_term_idx + n_terms_total;
-        kw_overflow_possible = want_hits > (uint64_t)max_hits;
-        kw_max_hits = max_hits;
-    }
+    // ---- K3 keyword side first, on its own stream
+    KwSide kws;
+    ORR_TRY(launch_keyword_side(idx, a, qoff, kws));
+    const orr::KwView kw = kws.view;
+    const size_t bm_bytes = kws.bm_bytes, bm_clean_before = kws.bm_clean_before;
+    const bool kw_overflow_possible = kws.overflow_possible;
+    const uint32_t kw_max_hits = kws.max_hits;
 
     g_ht.mark(1);
     // ---- cosine numerators
@@ -2510,34 +2567,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             HIP_TRY(orr::launch_rescore_exact(idx->d_emb, idx->dim, d_q, B, kprime, idx->row_base, d_cand, s));
         }
     } else {
-        // generic large-k path: full stable sort of every score, query by query
-        ORR_TRY(idx->ws_keys_a.reserve(sizeof(unsigned long long) * (size_t)n));
-        ORR_TRY(idx->ws_keys_b.reserve(sizeof(unsigned long long) * (size_t)n));
-        ORR_TRY(idx->ws_vals_a.reserve(sizeof(uint32_t) * (size_t)n));
-        ORR_TRY(idx->ws_vals_b.reserve(sizeof(uint32_t) * (size_t)n));
-        size_t tmp_bytes = 0;
-        HIP_TRY(orr::sort_pairs_desc(nullptr, tmp_bytes, idx->ws_keys_a.as<unsigned long long>(),
-                                     idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(),
-                                     idx->ws_vals_b.as<uint32_t>(), n, s));
-        ORR_TRY(idx->ws_sort_tmp.reserve(tmp_bytes));
-        for (int32_t b = 0; b < B; ++b) {
-            const double *dq = d_dot ? d_dot + (size_t)b * n : nullptr;
-            {
-                Timed t(idx, "score_keys", (double)n * 36.0);
-                HIP_TRY(orr::launch_score_keys(dq, idx->d_norm_b, idx->d_created, kw, b, qc[b], a.now_ticks, n,
-                                               idx->ws_keys_a.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(), s));
-            }
-            {
-                Timed t(idx, "radix_sort_desc", (double)n * 12.0 * 2.0 * 8.0);
-                size_t tb = idx->ws_sort_tmp.cap;
-                HIP_TRY(orr::sort_pairs_desc(idx->ws_sort_tmp.p, tb, idx->ws_keys_a.as<unsigned long long>(),
-                                             idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_a.as<uint32_t>(),
-                                             idx->ws_vals_b.as<uint32_t>(), n, s));
-            }
-            HIP_TRY(orr::launch_records_from_sorted(idx->ws_keys_b.as<unsigned long long>(), idx->ws_vals_b.as<uint32_t>(),
-                                                    kprime, n, idx->row_base, d_dot, n, idx->d_norm_b, idx->d_created,
-                                                    idx->d_row_ids, kw, b, 1, d_cand + (size_t)b * (kprime + 1), s));
-        }
+        ORR_TRY(run_large_k(idx, a, kprime, n, d_dot, kw, qc, d_cand, s));
     }
     if (!owner_of(idx)->dead.empty())      // records of deleted rows are dropped by the host finish
         HIP_TRY(orr::launch_mark_dead_records(d_cand, B, kprime, owner_of(idx)->d_dead.as<int64_t>(),
