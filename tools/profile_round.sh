@@ -4,9 +4,9 @@
 set -u
 cd "$(dirname "$0")/.." ; export TMPDIR=/tmp
 OUT=gpurun_out/prof ; rm -rf $OUT ; mkdir -p $OUT
-C3="bench.py --no-legs --no-overlap-leg --no-cpu-baseline --steps 10 --warmup 3"
-C2="bench.py --no-legs --no-overlap-leg --no-cpu-baseline --rows-per-gpu 1000000 --batch 1 --steps 20 --warmup 3"
-P256="bench.py --no-legs --no-overlap-leg --no-cpu-baseline --rows-per-gpu 262144 --batch 256 --steps 3 --warmup 1"
+C3="bench.py --no-legs --no-overlap-leg --no-cpu-baseline --no-pmc --steps 10 --warmup 3"
+C2="bench.py --no-legs --no-overlap-leg --no-cpu-baseline --no-pmc --rows-per-gpu 1000000 --batch 1 --steps 20 --warmup 3"
+P256="bench.py --no-legs --no-overlap-leg --no-cpu-baseline --no-pmc --rows-per-gpu 262144 --batch 256 --steps 3 --warmup 1"
 run() { name=$1; shift; echo "== $name: rocprofv3 $*" ; timeout -k 10 280 rocprofv3 --output-format csv "$@" > $OUT/$name.stdout 2> $OUT/$name.stderr; echo "rc=$?"; }
 run kt_c3   --kernel-trace --stats -d $OUT/kt_c3 -- python3 $C3
 tail -1 $OUT/kt_c3.stdout > $OUT/bench_c3_under_trace.json
