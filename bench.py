@@ -766,12 +766,12 @@ def run(args, probe, state, cluster_mode, world, rank):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
-        # (a collective that cannot complete -- a rank died -- raises after three minutes instead of the default ten, and the
+        # (a collective that cannot complete -- a rank died -- raises after five minutes instead of the default ten, and the
         # survivors report it in the JSON line)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
         state["dist"] = dist
     env = {"P": P, "torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank}
 
@@ -854,22 +854,6 @@ def run(args, probe, state, cluster_mode, world, rank):
         B = args.batch or 1024
         n_total = rows * world
         coll_dev = dev if args.backend == "nccl" else "cpu"
-        # ---- leg: FIXED corpus split over the ranks (strong scaling: the curve 1 -> N shows what sharding buys one batch),
-        # C3's corpus and batch: 10M rows in all, 256 hybrid queries per step.  Built, timed and freed before the headline shard.
-        if not args.no_legs and args.strong_rows >= world:
-            rows_s = args.strong_rows // world
-            t0 = time.perf_counter()
-            idx_s = build_shard(P, syn, torch, rank, rows_s, dim, rows_s * world, dev, args.set_option)
-            setup_s["strong_corpus"] = time.perf_counter() - t0
-            front_s = sharded.ShardedRecallSearch(idx_s, dim, coll_dev)
-            leg = Leg("strong", "fixed corpus (strong scaling): " + workload_label(rows_s, dim, 256, k, True, world), rows_s, rows_s * world, 256)
-            r = run_leg(leg, args, env, idx_s, front_s, syn)
-            r["scaling"] = "strong"
-            r["collectives_per_step"] = front_s.collectives / max(1, args.warmup + args.steps + min(5, args.steps))
-            legs_out[f"strong_{args.strong_rows // 1_000_000}M_rows_total_256_queries"] = r
-            idx_s.close()
-            del idx_s, front_s
-            torch.cuda.empty_cache()
         t0 = time.perf_counter()
         idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
         setup_s["headline_corpus"] = time.perf_counter() - t0
@@ -883,10 +867,14 @@ def run(args, probe, state, cluster_mode, world, rank):
         head["escalated_queries"] = front.escalated_queries
         if rank == 0:                              # the headline is in hand from here on: a later failure still reports it
             state["out"] = assemble(args, probe, head, {}, setup_s, None, None, rows, n_total, B, world, t_start, leg_errors)
+        def keep():                                # whatever is in hand goes into the line a later failure prints
+            if rank == 0:
+                state["out"] = assemble(args, probe, head, legs_out, setup_s, None, None, rows, n_total, B, world, t_start, leg_errors)
         if not args.no_legs:
             for bq in (1, 256):
                 leg = Leg(f"c4_b{bq}", workload_label(rows, dim, bq, k, False, world), rows, n_total, bq, terms=False)
                 legs_out[f"C4_cosine_only_{bq}_queries"] = run_leg(leg, args, env, idx, front, syn)
+                keep()
         # ---- leg: the same devices from ONE process through orr_cluster (rank 0 drives every device; the other ranks wait).  Small
         # shards: every device already holds its rank's 12.5M rows.
         if not args.no_legs and args.cluster_leg_rows > 0 and args.backend == "nccl":
@@ -897,7 +885,29 @@ def run(args, probe, state, cluster_mode, world, rank):
                 # the same with the records exchanged by ONE RCCL all-gather (orr_cluster "exchange" = 1) -- in a CHILD process: that
                 # path has never run on more than one device, and whatever it does must not take this job's record down with it
                 optional_leg(tag + "_rccl_exchange", lambda: cluster_child(args, world))
+                keep()
             dist.barrier()
+
+        # ---- leg: FIXED corpus split over the ranks (strong scaling: the curve 1 -> N shows what sharding buys one batch),
+        # C3's corpus and batch: 10M rows in all, 256 hybrid queries per step.  LAST: the headline shard is closed first (on up to four
+        # GPUs the two do not fit side by side), and whatever happens here the headline is already in hand.
+        if not args.no_legs and args.strong_rows >= world:
+            idx.close()
+            idx = None
+            torch.cuda.empty_cache()
+            rows_s = args.strong_rows // world
+            t0 = time.perf_counter()
+            idx_s = build_shard(P, syn, torch, rank, rows_s, dim, rows_s * world, dev, args.set_option)
+            setup_s["strong_corpus"] = time.perf_counter() - t0
+            front_s = sharded.ShardedRecallSearch(idx_s, dim, coll_dev)
+            leg = Leg("strong", "fixed corpus (strong scaling): " + workload_label(rows_s, dim, 256, k, True, world), rows_s, rows_s * world, 256)
+            r = run_leg(leg, args, env, idx_s, front_s, syn)
+            r["scaling"] = "strong"
+            r["collectives_per_step"] = front_s.collectives / max(1, args.warmup + args.steps + min(5, args.steps))
+            legs_out[f"strong_{args.strong_rows // 1_000_000}M_rows_total_256_queries"] = r
+            idx_s.close()
+            del idx_s, front_s
+            torch.cuda.empty_cache()
 
     cpu = parity = None
     if rank == 0 and world == 1 and not cluster_mode and not args.no_cpu_baseline:
