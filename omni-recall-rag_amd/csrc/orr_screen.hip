@@ -866,12 +866,20 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
         else { s_k = T; s_src += (int64_t)n_main * kScImage; }
     }
     ORR_STAMP(7);
-    // the last RING K-tiles: r-th of them leaves RING - 2 - r tiles in flight (the last one waits for nothing: 63)
+    // the last RING K-tiles: r-th of them leaves RING - 2 - r tiles in flight (the last one waits for nothing: 63).
+    // The epilogue's loads (kEpiLoads vector-memory instructions per wave: 8 row constants x 2, 16 count words, the query
+    // constants) go out in the tail K-tile kHookR, FOUR K-tiles before the end for the row requesters, three for the query
+    // requesters (round 2: two): under a C3 launch the rows' constants took longer than two K-tiles to arrive and the epilogue
+    // began with 2,000 cycles of waiting for them.  They are younger than every ring request still in flight, and a wave's
+    // loads return in order, so the counted waits behind the hook simply allow kEpiLoads more to be outstanding.
+    constexpr int kEpiLoads = 33, kHookR = RING >= 4 ? RING - 4 : 0;
     auto tail = [&](auto self, auto r_c) __attribute__((always_inline)) {
         constexpr int r = decltype(r_c)::value;
         if constexpr (r < RING) {
-            using WaitTail = std::integral_constant<int, (r <= RING - 2 ? KP * (RING - 2 - r) : 63)>;
-            using Hook = std::integral_constant<bool, r == RING - 2>;
+            constexpr int ring_left = r <= RING - 2 ? KP * (RING - 2 - r) : 63;
+            constexpr int allowed = r > kHookR && !DOTS ? ring_left + kEpiLoads : ring_left;
+            using WaitTail = std::integral_constant<int, (allowed > 63 ? 63 : allowed)>;
+            using Hook = std::integral_constant<bool, r == kHookR>;
             tile_iter(std::false_type{}, std::false_type{}, WaitTail{}, Hook{});
             self(self, std::integral_constant<int, r + 1>{});
         }
