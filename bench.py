@@ -380,7 +380,7 @@ def run_leg(leg, args, env, idx, front, gen, overlap=False):
 def _committed_traffic(kernel, rows, dim, B):
     """HBM bytes per launch from this round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), only where the shape matches."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
     if not os.path.exists(path):
         return None, None, 1
     try:
@@ -388,7 +388,7 @@ def _committed_traffic(kernel, rows, dim, B):
             doc = json.load(f)
         for e in doc.get("entries", []):
             if e.get("kernel") == kernel and e.get("rows") == rows and e.get("dim") == dim and e.get("batch") == B:
-                return (e.get("hbm_bytes_per_launch_corrected"), "profiles/r02_pmc_hbm_traffic.json (" + e.get("command", "") + ")",
+                return (e.get("hbm_bytes_per_launch_corrected"), "profiles/r03_pmc_hbm_traffic.json (" + e.get("command", "") + ")",
                         int(e.get("launches_per_step", 1)))
     except Exception:
         pass
