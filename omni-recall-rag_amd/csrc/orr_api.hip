@@ -1977,6 +1977,100 @@ int run_large_k(orr_index *idx, const BatchArgs &a, int32_t kprime, int64_t n, c
     return ORR_OK;
 }
 
+// up to this many queries the tail of the two-stage pass is one launch (finish_survivors)
+constexpr int kFinishFusedMaxB = 256;
+constexpr int kRetryPass = 1;          // run_shard_once: a workspace was too small and has been enlarged; the same pass again
+
+// The tail of the two-stage pass: exact re-score of every buffered survivor (fp32 master, reference arithmetic), the best k' of
+// them as records with their exact dots.  Up to kFinishFusedMaxB queries one launch (finish_survivors: four lanes per survivor,
+// the workgroup that draws a query's last ticket merges its lists and writes the records, straight into pinned host memory when
+// the record set is small); beyond, four launches.  The survivors' counts go back with the records (idx->pin_cnt).
+int two_stage_tail(orr_index *idx, const BatchArgs &a, int32_t kprime, int64_t n, const float *d_q, const orr::KwView &kw,
+                   const orr::FusedEpilogue &epi, uint32_t kCap, int32_t buf_lists, bool host_records, size_t rec_bytes,
+                   orr_candidate **d_cand_io, bool *direct_host_io, hipStream_t s)
+{
+    const int32_t B = a.B;
+    orr_candidate *d_cand = *d_cand_io;
+    ORR_TRY(idx->ws_fdot.reserve(sizeof(double) * (size_t)B * kCap));
+    ORR_TRY(idx->pin_cnt.reserve(sizeof(uint32_t) * (size_t)B));
+    if (B <= kFinishFusedMaxB && idx->dim % 256 == 0) {
+        // the tail in one launch; small record sets go straight into pinned host memory (they are final when written)
+        if (host_records && !a.out_dev && rec_bytes <= (256u << 10)) {
+            ORR_TRY(idx->pin_cand.reserve(rec_bytes));
+            d_cand = idx->pin_cand.as<orr_candidate>();
+            *direct_host_io = true;
+        }
+        Timed t(idx, "finish_survivors", 0.0);
+        HIP_TRY(orr::launch_finish_survivors(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                             idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, idx->ws_fcnt.as<uint32_t>() + 2 * B,
+                                             kCap, epi.buf, idx->ws_fdot.as<double>(), idx->ws_sel.as<orr::SelEntry>(), kprime, n,
+                                             idx->row_base, idx->ws_tsL.as<double>(), d_cand, idx->pin_cnt.as<uint32_t>(), s));
+    } else {
+        {
+            Timed t(idx, "rescore_buffer_exact", 0.0);
+            HIP_TRY(orr::launch_rescore_buffer_exact(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, kw,
+                                                     idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf,
+                                                     idx->ws_fdot.as<double>(), s));
+        }
+        {
+            Timed t(idx, "buffer_to_lists", 0.0);
+            HIP_TRY(orr::launch_buffer_to_lists(epi.buf, epi.cnt, kCap, B, 0, buf_lists, idx->ws_sel.as<orr::SelEntry>(), s));
+        }
+        {
+            Timed t(idx, "select_final", (double)B * (double)buf_lists * orr::kSelWidth * sizeof(orr::SelEntry));
+            HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), buf_lists, B, kprime, n, idx->row_base,
+                                             nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
+                                             0, 0.0, nullptr, epi.cnt, kCap, idx->ws_tsL.as<double>(), d_cand, s));
+        }
+        {   // the records' exact dots come out of the buffer: no second K6 pass
+            Timed t(idx, "records_dot_from_buffer", 0.0);
+            HIP_TRY(orr::launch_records_dot_from_buffer(epi.buf, idx->ws_fdot.as<double>(), epi.cnt, kCap, B, kprime, idx->row_base,
+                                                        d_cand, s));
+        }
+        // the survivors' counts go back with the records: per-query escalation and orr_index_search_stats
+        HIP_TRY(hipMemcpyAsync(idx->pin_cnt.p, epi.cnt, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    }
+    *d_cand_io = d_cand;
+    return ORR_OK;
+}
+
+// The int8 screening GEMM (K2j) with the fused scoring epilogue over all participating rows, in n_ranges row ranges: the later
+// ranges' count words are formed on the keyword stream while the earlier ranges are multiplied (released when the main
+// stream gets here), every launch draws its output tiles from its own set of tickets.
+int screen_i8_in_ranges(orr_index *idx, const BatchArgs &a, int64_t n, const orr::KwView &kw, orr::FusedEpilogue epi, int n_ranges,
+                        const int64_t *range_row, double plane_bytes_per_row, hipStream_t s)
+{
+    const int32_t B = a.B;
+    // algorithmic bytes: the int8 rows once, per row its constants (rowc 16 B, i8_rowf 16 B) and, with query terms,
+    // 16 B of count words per 32 queries; the query image once
+    if (n_ranges > 1) {
+        // the later ranges' count words: released when the main stream reaches the first range's GEMM
+        hipStream_t k = idx->stream_kw;
+        HIP_TRY(hipEventRecord(idx->ev_main_ready, s));
+        HIP_TRY(hipStreamWaitEvent(k, idx->ev_main_ready, 0));
+        for (int r = 1; r < n_ranges; ++r) {
+            {
+                Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[r + 1] - range_row[r]), k);
+                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), k, range_row[r],
+                                                       range_row[r + 1], epi.count_bits == 2 ? 2 : 4));
+            }
+            HIP_TRY(hipEventRecord(idx->ev_range[r - 1], k));
+        }
+    }
+    // output-tile tickets of the 16 x 16 x 64 form: eight counters per launch, cleared once per pass
+    ORR_TRY(idx->ws_tickets.reserve(sizeof(uint32_t) * 8 * 16));
+    HIP_TRY(hipMemsetAsync(idx->ws_tickets.p, 0, sizeof(uint32_t) * 8 * 16, s));
+    for (int r = 0; r < n_ranges; ++r) {
+        if (r > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_range[r - 1], 0));
+        epi.tickets = idx->ws_tickets.as<uint32_t>() + 8 * r;
+        const double rows_r = (double)(range_row[r + 1] - range_row[r]);
+        Timed t(idx, "screen_i8_fused", rows_r * ((double)idx->dim + 32.0 + (epi.count_planes ? (epi.count_bits == 2 ? 8.0 : 16.0) * (double)((B + 31) / 32) : 0.0)) +
+                                        1.0 * (double)B * idx->dim);
+        HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, range_row[r + 1], idx->dim, epi, s, range_row[r]));
+    }
+    return ORR_OK;
+}
+
 // Device side of one batch: exact dots, keyword bitmaps, fused scores, selection.
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
@@ -1984,8 +2078,6 @@ int run_large_k(orr_index *idx, const BatchArgs &a, int32_t kprime, int64_t n, c
 // up to this many queries the tail of the two-stage pass is one launch (finish_survivors: four lanes per survivor; 1M x 3072
 // rows, 128 / 256 queries: 1.016 -> 0.984 / 1.43 -> 1.39 ms per batch; 10M rows x 256: even; beyond, the survivors of a batch
 // are too many for four lanes each)
-constexpr int kFinishFusedMaxB = 256;
-constexpr int kRetryPass = 1;          // run_shard_once: a workspace was too small and has been enlarged; the same pass again
 
 int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
                    const orr_candidate **recs_host)
@@ -2307,7 +2399,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             int64_t range_row[17];
             range_row[0] = 0;
             for (int r = 1; r <= 16; ++r) range_row[r] = n;
-            const double plane_bytes_per_row = 4.0 * orr::kCountPlanes * (double)((B + 31) / 32);
+            double plane_bytes_per_row = 4.0 * orr::kCountPlanes * (double)((B + 31) / 32);
             if (kw.bitmaps && !ts_gemv) {
                 ORR_TRY(idx->ws_fany.reserve(sizeof(uint32_t) * orr::kCountPlanes * (size_t)((B + 31) / 32) * (size_t)epi.plane_stride));
                 if (prefix_i8 && two_stage && n >= (int64_t)2000000) {
@@ -2319,8 +2411,16 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     constexpr int64_t kRound = 256 * 256;
                     for (int r = 1; r < n_ranges; ++r) range_row[r] = (n * r / n_ranges + kRound / 2) / kRound * kRound;
                 }
+                // two-bit count words where every query has at most three terms and the 16 x 16 x 64 form screens (its epilogue reads
+                // them): half the words written here and read there
+                uint32_t max_terms = 0;
+                for (int32_t b = 0; b < B; ++b) max_terms = std::max(max_terms, qoff[(size_t)b + 1] - qoff[(size_t)b]);
+                if (max_terms <= 3 && idx->opt_two_stage == 1 && two_stage && prefix_i8 && orr::screen_i8_uses_tile16(B, n, idx->dim, epi.plane_stride) &&
+                    !getenv("ORR_COUNT_BITS4"))
+                    epi.count_bits = 2;
+                plane_bytes_per_row = (epi.count_bits == 2 ? 8.0 : 16.0) * (double)((B + 31) / 32);
                 Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[1] - range_row[0]));
-                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, 0, range_row[1]));
+                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, 0, range_row[1], epi.count_bits == 2 ? 2 : 4));
                 epi.count_planes = idx->ws_fany.as<uint32_t>();
             }
             epi.qf = idx->ws_fqf.as<float4>();
@@ -2414,7 +2514,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
                 if (n_ranges > 1 && !gemm_i8) {         // (ranges were planned for the int8 GEMM: the other forms take one launch)
                     Timed t(idx, "count_planes", plane_bytes_per_row * (double)(n - range_row[1]));
-                    HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, range_row[1], n));
+                    HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), s, range_row[1], n, epi.count_bits == 2 ? 2 : 4));
                     n_ranges = 1;
                 }
                 if (gemm_i8) {
@@ -2422,33 +2522,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                         ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
                         HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
                     }
-                    // algorithmic bytes: the int8 rows once, per row its constants (rowc 16 B, i8_rowf 16 B) and, with query terms,
-                    // 16 B of count words per 32 queries; the query image once
-                    if (n_ranges > 1) {
-                        // the later ranges' count words: released when the main stream reaches the first range's GEMM
-                        hipStream_t k = idx->stream_kw;
-                        HIP_TRY(hipEventRecord(idx->ev_main_ready, s));
-                        HIP_TRY(hipStreamWaitEvent(k, idx->ev_main_ready, 0));
-                        for (int r = 1; r < n_ranges; ++r) {
-                            {
-                                Timed t(idx, "count_planes", plane_bytes_per_row * (double)(range_row[r + 1] - range_row[r]), k);
-                                HIP_TRY(orr::launch_query_count_planes(kw, B, n, epi.plane_stride, idx->ws_fany.as<uint32_t>(), k, range_row[r],
-                                                                       range_row[r + 1]));
-                            }
-                            HIP_TRY(hipEventRecord(idx->ev_range[r - 1], k));
-                        }
-                    }
-                    // output-tile tickets of the 16 x 16 x 64 form: eight counters per launch, cleared once per pass
-                    ORR_TRY(idx->ws_tickets.reserve(sizeof(uint32_t) * 8 * 16));
-                    HIP_TRY(hipMemsetAsync(idx->ws_tickets.p, 0, sizeof(uint32_t) * 8 * 16, s));
-                    for (int r = 0; r < n_ranges; ++r) {
-                        if (r > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_range[r - 1], 0));
-                        epi.tickets = idx->ws_tickets.as<uint32_t>() + 8 * r;
-                        const double rows_r = (double)(range_row[r + 1] - range_row[r]);
-                        Timed t(idx, "screen_i8_fused", rows_r * ((double)idx->dim + 32.0 + (epi.count_planes ? 16.0 * (double)((B + 31) / 32) : 0.0)) +
-                                                        1.0 * (double)B * idx->dim);
-                        HIP_TRY(orr::launch_screen_i8(idx->ws_qtiled.p, B, idx->emb_i8.p, range_row[r + 1], idx->dim, epi, s, range_row[r]));
-                    }
+                    ORR_TRY(screen_i8_in_ranges(idx, a, n, kw, epi, n_ranges, range_row, plane_bytes_per_row, s));
                 } else if (ts_i8) {
                     Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 28.0 * (double)n + 2.0 * (double)B * idx->dim);   // per row: scale, two relative norms (12 B), normB and created (16 B)
                     HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
@@ -2466,45 +2540,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     Timed t(idx, "gemm_dot_bf16x1_fused", 4.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, n, idx->dim, nullptr, 0, &epi, 1, s));
                 }
-                ORR_TRY(idx->ws_fdot.reserve(sizeof(double) * (size_t)B * kCap));
-                ORR_TRY(idx->pin_cnt.reserve(sizeof(uint32_t) * (size_t)B));
-                if (B <= kFinishFusedMaxB && idx->dim % 256 == 0) {
-                    // the tail in one launch; small record sets go straight into pinned host memory (they are final when written)
-                    if (host_records && !a.out_dev && rec_bytes <= (256u << 10)) {
-                        ORR_TRY(idx->pin_cand.reserve(rec_bytes));
-                        d_cand = idx->pin_cand.as<orr_candidate>();
-                        direct_host = true;
-                    }
-                    Timed t(idx, "finish_survivors", 0.0);
-                    HIP_TRY(orr::launch_finish_survivors(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                                         idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, idx->ws_fcnt.as<uint32_t>() + 2 * B,
-                                                         kCap, epi.buf, idx->ws_fdot.as<double>(), idx->ws_sel.as<orr::SelEntry>(), kprime, n,
-                                                         idx->row_base, idx->ws_tsL.as<double>(), d_cand, idx->pin_cnt.as<uint32_t>(), s));
-                } else {
-                    {
-                        Timed t(idx, "rescore_buffer_exact", 0.0);
-                        HIP_TRY(orr::launch_rescore_buffer_exact(idx->d_emb, idx->dim, d_q, B, idx->d_norm_b, idx->d_created, kw,
-                                                                 idx->ws_qc.as<orr::QueryConst>(), a.now_ticks, epi.cnt, kCap, epi.buf,
-                                                                 idx->ws_fdot.as<double>(), s));
-                    }
-                    {
-                        Timed t(idx, "buffer_to_lists", 0.0);
-                        HIP_TRY(orr::launch_buffer_to_lists(epi.buf, epi.cnt, kCap, B, 0, buf_lists, idx->ws_sel.as<orr::SelEntry>(), s));
-                    }
-                    {
-                        Timed t(idx, "select_final", (double)B * (double)buf_lists * orr::kSelWidth * sizeof(orr::SelEntry));
-                        HIP_TRY(orr::launch_select_final(idx->ws_sel.as<orr::SelEntry>(), buf_lists, B, kprime, n, idx->row_base,
-                                                         nullptr, nullptr, 0, idx->d_norm_b, idx->d_created, idx->d_row_ids, kw,
-                                                         0, 0.0, nullptr, epi.cnt, kCap, idx->ws_tsL.as<double>(), d_cand, s));
-                    }
-                    {   // the records' exact dots come out of the buffer: no second K6 pass
-                        Timed t(idx, "records_dot_from_buffer", 0.0);
-                        HIP_TRY(orr::launch_records_dot_from_buffer(epi.buf, idx->ws_fdot.as<double>(), epi.cnt, kCap, B, kprime, idx->row_base,
-                                                                    d_cand, s));
-                    }
-                    // the survivors' counts go back with the records: per-query escalation and orr_index_search_stats
-                    HIP_TRY(hipMemcpyAsync(idx->pin_cnt.p, epi.cnt, sizeof(uint32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
-                }
+                ORR_TRY(two_stage_tail(idx, a, kprime, n, d_q, kw, epi, kCap, buf_lists, host_records, rec_bytes, &d_cand, &direct_host, s));
                 records_have_dots = true;
                 a.used_two_stage = true;
                 pass_mode = (gemm_i8 || ts_i8) ? 1 : (((ts_gemv && !ts_i8) || (idx->opt_two_stage == 1 && idx->shadow_ready)) ? 2 : 3);

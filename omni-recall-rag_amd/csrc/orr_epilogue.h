@@ -314,12 +314,15 @@ struct EpiTileLoads16 {
 
 // Word offsets of this lane's count words inside a plane pair: its row (clamped) plus, where g >> 1 is set, the distance to the
 // next plane (word 2 t + 1 instead of 2 t).  32 bits: the launcher sends shards whose planes exceed 2^30 words elsewhere.
+// (BITS = 2: two-bit count words -- word t of a block holds queries 16 t .. 16 t + 15, so every lane reads words 0 and 1 and its
+// four counts of tile t sit in byte g of word t; no half-plane offset.)
+template <int BITS = 4>
 __device__ __forceinline__ void epilogue_word_offsets16(uint32_t (&at)[8], int64_t colbase, int32_t B, int64_t n_rows, const FusedEpilogue &epi,
                                                         int lane)
 {
     const int c = tile16_c_of(lane), g = tile16_g_of(lane);
     const int32_t n_qg = (B + 31) >> 5;
-    const uint32_t plane_dist = epi.count_planes ? (uint32_t)((int64_t)n_qg * epi.plane_stride) : 0u;
+    const uint32_t plane_dist = epi.count_planes && BITS == 4 ? (uint32_t)((int64_t)n_qg * epi.plane_stride) : 0u;
     // (32-bit arithmetic throughout: the launcher sends shards of 2^28 rows and more elsewhere)
     const uint32_t col0 = (uint32_t)colbase + (uint32_t)c, last = (uint32_t)(n_rows - 1), half = (uint32_t)(g >> 1) * plane_dist;
 #pragma unroll
@@ -330,6 +333,7 @@ __device__ __forceinline__ void epilogue_word_offsets16(uint32_t (&at)[8], int64
 }
 
 // this lane's two count words per row tile for block b of 32 queries, already shifted to its half (nibble e = query 4 g + e)
+template <int BITS = 4>
 __device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const uint32_t (&at)[8], int b, int qbase, int32_t B,
                                                       const FusedEpilogue &epi)
 {
@@ -340,7 +344,7 @@ __device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         // the plane of word 2 t of (query group): a wave-uniform base; the lane's offset picks word 2 t or 2 t + 1
-        const uint32_t *plane = has_cp ? epi.count_planes + ((int64_t)(2 * t) * n_qg + qgc) * epi.plane_stride
+        const uint32_t *plane = has_cp ? epi.count_planes + ((int64_t)(BITS == 2 ? t : 2 * t) * n_qg + qgc) * epi.plane_stride
                                        : reinterpret_cast<const uint32_t *>(epi.rowc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -350,6 +354,7 @@ __device__ __forceinline__ void epilogue_load_words16(uint32_t (&w)[8][2], const
     }
 }
 
+template <int BITS = 4>
 __device__ __forceinline__ void epilogue_issue_loads16(EpiTileLoads16 &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                        const FusedEpilogue &epi, int lane)
 {
@@ -362,18 +367,19 @@ __device__ __forceinline__ void epilogue_issue_loads16(EpiTileLoads16 &L, int qb
         L.rf[j] = load_global_at_f4(epi.i8_rowf, off);
     }
     uint32_t at[8];
-    epilogue_word_offsets16(at, colbase, B, n_rows, epi, lane);
-    epilogue_load_words16(L.w[0], at, 0, qbase, B, epi);
+    epilogue_word_offsets16<BITS>(at, colbase, B, n_rows, epi, lane);
+    epilogue_load_words16<BITS>(L.w[0], at, 0, qbase, B, epi);
 }
 
 // the count words of the blocks 1..3 (behind the K loop: beside the fragments their 48 landing registers did not fit)
+template <int BITS = 4>
 __device__ __forceinline__ void epilogue_issue_later_words16(EpiTileLoads16 &L, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                              const FusedEpilogue &epi, int lane)
 {
     uint32_t at[8];
-    epilogue_word_offsets16(at, colbase, B, n_rows, epi, lane);
+    epilogue_word_offsets16<BITS>(at, colbase, B, n_rows, epi, lane);
 #pragma unroll
-    for (int b = 1; b < 4; ++b) epilogue_load_words16(L.w[b], at, b, qbase, B, epi);
+    for (int b = 1; b < 4; ++b) epilogue_load_words16<BITS>(L.w[b], at, b, qbase, B, epi);
 }
 
 // Registers: the 256 accumulators fill the accumulation file, so everything here has to fit the 256 vector registers with
@@ -439,6 +445,17 @@ __device__ __forceinline__ float count_of_nibble(uint32_t x, uint32_t y)
     return r;
 }
 
+template <int BYTE>
+__device__ __forceinline__ float ubyte_as_float(uint32_t v)
+{
+    float r;
+    if constexpr (BYTE == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
+    else if constexpr (BYTE == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
+    else if constexpr (BYTE == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // Pass 1 of this epilogue, round 3.  The test of one (query, row) pair is
 //     upper = a (qx rb_j) + m qz + cjw_j  >=  qy            cjw_j = recency_j + row bound_j + QW eb_j
 // with QW = the LARGEST query-side quantisation term of the batch's (finite) queries instead of the pair's own (eb_j >= 0, so
@@ -455,7 +472,9 @@ __device__ __forceinline__ float count_of_nibble(uint32_t x, uint32_t y)
 // query with anything non-finite into qx = qz = 0, qy = -inf (every pair passes); a slot without a query has qy = +inf.
 // a is an integer dot (|a| <= 3072 * 127^2), rb <= 1e30 and qx <= 1: no product overflows; inf - inf only arises for pairs
 // that are to be dropped (row past the end and keep-everything query; no query and keep-everything row).
-template <int QDEPTH, typename HOOK = EpiNoHook>
+// BITS = 2: two-bit count words (a batch whose queries all have at most three terms): half the words to load, the lane's four
+// counts of a tile are one byte of the word, spread to four bytes with one multiplication.
+template <int QDEPTH, typename HOOK = EpiNoHook, int BITS = 4>
 __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64_t colbase, int32_t B, int64_t n_rows,
                                                  const FusedEpilogue &epi, int lane, EpiParked *queue, int queue_stride, uint32_t idx_salt,
                                                  unsigned long long *st, const EpiTileLoads16 &L, const float4 *qf_lds,
@@ -502,13 +521,22 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
             }
             static_for<4>([&](auto jp_c) {
                 constexpr int jp = decltype(jp_c)::value, j0 = 2 * jp;
-                // the count words of rows j0, j0 + 1: nibble e -> byte (e >> 1) of x (even e) or y (odd e)
-                const uint32_t w0 = L.w[b][j0][t] >> sh, w1 = L.w[b][j0 + 1][t] >> sh;
-                const uint32_t x0 = w0 & 0x0F0F0F0Fu, y0 = (w0 >> 4) & 0x0F0F0F0Fu, x1 = w1 & 0x0F0F0F0Fu, y1 = (w1 >> 4) & 0x0F0F0F0Fu;
+                // the count words of rows j0, j0 + 1: nibble e -> byte (e >> 1) of x (even e) or y (odd e); two-bit words: field e -> byte e of x
+                uint32_t x0, y0, x1, y1;
+                if constexpr (BITS == 2) {
+                    x0 = (__builtin_amdgcn_ubfe(L.w[b][j0][t], 8u * (uint32_t)g, 8u) * 0x41041u) & 0x03030303u;
+                    x1 = (__builtin_amdgcn_ubfe(L.w[b][j0 + 1][t], 8u * (uint32_t)g, 8u) * 0x41041u) & 0x03030303u;
+                    y0 = y1 = 0u;
+                } else {
+                    const uint32_t w0 = L.w[b][j0][t] >> sh, w1 = L.w[b][j0 + 1][t] >> sh;
+                    x0 = w0 & 0x0F0F0F0Fu; y0 = (w0 >> 4) & 0x0F0F0F0Fu; x1 = w1 & 0x0F0F0F0Fu; y1 = (w1 >> 4) & 0x0F0F0F0Fu;
+                }
                 static_for<4>([&](auto e_c) {
                     constexpr int e = decltype(e_c)::value;
                     const f32x2e a2 = {acc16_as_float<4 * (8 * (2 * b + t) + j0) + e>(acc_token), acc16_as_float<4 * (8 * (2 * b + t) + j0 + 1) + e>(acc_token)};
-                    const f32x2e m2 = {count_of_nibble<e>(x0, y0), count_of_nibble<e>(x1, y1)};
+                    f32x2e m2;
+                    if constexpr (BITS == 2) m2 = f32x2e{ubyte_as_float<e>(x0), ubyte_as_float<e>(x1)};
+                    else m2 = f32x2e{count_of_nibble<e>(x0, y0), count_of_nibble<e>(x1, y1)};
                     const f32x2e t1 = a2 * rb2[jp];
                     const f32x2e t2 = __builtin_elementwise_fma(t1, qx2[e], cjw2[jp]);
                     const f32x2e t3 = __builtin_elementwise_fma(m2, qz2[e], t2);
@@ -535,8 +563,8 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
             // Its count words come from memory again: kept in registers since pass 1a they were 64 more live values for a rare
             // path.
             uint32_t at1[8], w1[8][2];
-            epilogue_word_offsets16(at1, colbase, B, n_rows, epi, lane);
-            epilogue_load_words16(w1, at1, b, qbase, B, epi);
+            epilogue_word_offsets16<BITS>(at1, colbase, B, n_rows, epi, lane);
+            epilogue_load_words16<BITS>(w1, at1, b, qbase, B, epi);
             static_for<8>([&](auto te_c) {
                 constexpr int te = decltype(te_c)::value, t = te >> 2, e = te & 3, i = 2 * b + t;
                 if ((group_flags & (1u << (8 * b + te))) == 0u) return;
@@ -545,7 +573,7 @@ __device__ __forceinline__ void fused_epilogue16(int acc_token, int qbase, int64
                 const bool has_query = qi < B;
                 static_for<8>([&](auto j_c) {
                     constexpr int j = decltype(j_c)::value;
-                    const uint32_t m = ((w1[j][t] >> sh) >> (4 * e)) & 15u;
+                    const uint32_t m = BITS == 2 ? (w1[j][t] >> (8 * g + 2 * e)) & 3u : ((w1[j][t] >> sh) >> (4 * e)) & 15u;
                     const float a = acc16_as_float_here<4 * (8 * i + j) + e>(token_1b);
                     const float upper = __builtin_fmaf((float)m, q1.z, __builtin_fmaf(a * rb2[j >> 1][j & 1], q1.x, cjw2[j >> 1][j & 1]));
                     const bool drop = upper < q1.y || !has_query || !(col0 + j * 16 < n_rows);

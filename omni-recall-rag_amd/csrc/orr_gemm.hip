@@ -253,16 +253,20 @@ __global__ __launch_bounds__(512, 2) void gemm_dot_bf16x3_kernel(const __bf16 *_
 // per word, ripple carry through the planes -- then each plane of each word, a 32 x 32 bit matrix with
 // queries down the lanes and rows along the bits, is transposed across the lanes with five exchange
 // steps, after which lane (r, h) holds the word of row r.  words_per_term % 4 == 0.
+// BITS = 2: counts of 0..3 (the launcher's caller guarantees at most three terms per query): two planes, and two output words per
+// (32 queries, row) -- word kk = queries 16 kk .. 16 kk + 15, two bits each.
+template <int BITS>
 __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride,
                                                                 uint32_t *__restrict__ planes, int64_t oct_first, int64_t oct_end)
 {
+    constexpr int kCountPlanes = BITS;                                     // (shadows orr::kCountPlanes: planes of THIS form)
     const int g = blockIdx.y;
     const int32_t n_qg = gridDim.y;
     const int lane = threadIdx.x & 63, q = lane & 31, h = lane >> 5;
     const int b = g * 32 + q;
     uint32_t t0 = 0, t1 = 0;
     if (b < B) { t0 = kw.q_term_off[b]; t1 = kw.q_term_off[b + 1]; }
-    const bool saturate = t1 - t0 > 15u;
+    const bool saturate = BITS == 4 && t1 - t0 > 15u;
     const int64_t n_quads = kw.words_per_term >> 2;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t pr = oct_first + wave_id; pr < oct_end; pr += n_waves) {
@@ -310,7 +314,24 @@ __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int3
                 c[k][p] = x;
             }
             const int64_t row = (Q * 4 + k) * 32 + q;                      // after the transpose this lane holds row q of the word
-            if (row < n_rows) {
+            if (BITS == 2) {
+                if (row < n_rows) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        uint32_t wv = 0u;
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            uint32_t x = (c[k][p] >> (16 * kk)) & 0xFFFFu;   // 16 queries' bits of plane p
+                            x = (x | (x << 8)) & 0x00FF00FFu;
+                            x = (x | (x << 4)) & 0x0F0F0F0Fu;
+                            x = (x | (x << 2)) & 0x33333333u;
+                            x = (x | (x << 1)) & 0x55555555u;              // bit n -> bit 2 n
+                            wv |= x << p;
+                        }
+                        planes[((int64_t)kk * n_qg + g) * plane_stride + row] = wv;
+                    }
+                }
+            } else if (row < n_rows) {
                 // planes -> NIBBLES: word kk holds the counts of queries 8 kk .. 8 kk + 7 of the group, four bits each (bit p of a
                 // nibble = plane p), so that the epilogue gets a pair's count with one v_bfe_u32 (orr_epilogue.h) instead of
                 // gathering four plane bits
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(256) void query_count_planes_kernel(KwView kw, int3
 }
 
 hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s,
-                                     int64_t row_first, int64_t row_end)
+                                     int64_t row_first, int64_t row_end, int32_t bits)
 {
     if (B <= 0 || !kw.bitmaps || n_rows <= 0) return hipSuccess;
     if (kw.words_per_term % 4 != 0 || row_first % 256 != 0) return hipErrorInvalidValue;
@@ -343,8 +364,12 @@ hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64
     if (oct_end <= oct_first) return hipSuccess;
     int64_t bx = (oct_end - oct_first + 3) / 4;                            // 4 waves per workgroup
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(query_count_planes_kernel, dim3((unsigned)bx, (unsigned)((B + 31) / 32)), dim3(256), 0, s, kw, B, n_rows,
-                       plane_stride, planes, oct_first, oct_end);
+    if (bits == 2)
+        hipLaunchKernelGGL(query_count_planes_kernel<2>, dim3((unsigned)bx, (unsigned)((B + 31) / 32)), dim3(256), 0, s, kw, B, n_rows,
+                           plane_stride, planes, oct_first, oct_end);
+    else
+        hipLaunchKernelGGL(query_count_planes_kernel<4>, dim3((unsigned)bx, (unsigned)((B + 31) / 32)), dim3(256), 0, s, kw, B, n_rows,
+                           plane_stride, planes, oct_first, oct_end);
     return hipGetLastError();
 }
 

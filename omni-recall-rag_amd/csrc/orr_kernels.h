@@ -214,6 +214,7 @@ struct FusedEpilogue {
     SelEntry *buf;                     // [B][cap]
     uint32_t cap;
     unsigned long long *stamps;        // diagnostic (ORR_SCREEN_STAMPS=file): s_memtime at the phases of every output tile, else null
+    int32_t count_bits;                // 4 (or 0: the same): count words as described above; 2: TWO bits per (query,row) -- word kk = queries 16 kk .. 16 kk + 15 of the group, two words per (32 queries, row) -- for batches whose queries all have at most three terms (the 16 x 16 x 64 form only)
     const float4 *qf16;                // [B] the 16 x 16 x 64 form's staged constants: qf with everything finite and .w = the batch's largest query bound term (launch_fused_query_consts)
     uint32_t *tickets;                 // [8] zeroed counters of ONE launch of the 16 x 16 x 64 screening GEMM (output tiles beyond a workgroup's first two are drawn from them), or null: static assignment
 };
@@ -223,8 +224,11 @@ hipError_t launch_split_queries(const float *Q, int32_t B, int32_t D, void *q_sp
 hipError_t launch_gemm_dot_bf16x3(const void *q_split_ws, int32_t B, const float *E, int64_t row_first, int64_t n_rows, int32_t D,
                                   float *S, int64_t s_stride, const FusedEpilogue *epi, int32_t products, hipStream_t s);
 // rows [row_first, row_end) only (row_first % 256 == 0; row_end < 0: to the end)
+// bits = 2: two-bit counts (every query of the batch has at most three terms), half the words (see FusedEpilogue::count_bits)
 hipError_t launch_query_count_planes(KwView kw, int32_t B, int64_t n_rows, int64_t plane_stride, uint32_t *planes, hipStream_t s,
-                                     int64_t row_first = 0, int64_t row_end = -1);
+                                     int64_t row_first = 0, int64_t row_end = -1, int32_t bits = 4);
+// whether launch_screen_i8 runs its 16 x 16 x 64 form for this shape (the only form that reads two-bit count words)
+bool screen_i8_uses_tile16(int32_t B, int64_t n_rows, int32_t D, int64_t plane_stride);
 // qf16 (optional, [B]): the same constants made safe for a NaN-dropping test (fused_epilogue16) -- finite qx / qz, a query with
 // anything non-finite turned into "every pair passes" (qx = qz = 0, floor -inf) -- with .w = the largest finite query bound
 // term of the batch in EVERY entry.

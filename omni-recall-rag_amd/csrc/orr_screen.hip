@@ -634,7 +634,8 @@ __global__ __launch_bounds__(256, 1) void screen_tile4_kernel(const __bf16 *__re
 // the 16-row x 4-chunk reads conflict-free on it.  The epilogue for this accumulator layout: fused_epilogue16 (orr_epilogue.h).
 // ---------------------------------------------------------------------------
 // DOTS (diagnostic, orr_index_screen_i8_dots): no scoring epilogue -- the raw int32 accumulators go to S[query][row].
-template <bool NT, bool DOTS = false>
+// BITS2: the count words hold two bits per (query,row) (FusedEpilogue::count_bits == 2).
+template <bool NT, bool DOTS = false, bool BITS2 = false>
 __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__restrict__ Qh, int32_t B,
                                                               const __bf16 *__restrict__ Eh, int64_t row_first, int64_t n_rows,
                                                               int32_t D, float *__restrict__ S, int64_t s_stride,
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             asm volatile("" : "+s"(ep.kw.bitmaps), "+s"(ep.kw.words_per_term), "+s"(ep.kw.q_term_idx), "+s"(ep.kw.q_term_off));
             const int q = b0 + tid;
             qf_mine = load_global(ep.qf16, (uint32_t)(q < B ? q : B - 1));      // (the NaN-safe constants with the batch's QW in .w)
-            epilogue_issue_loads16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);
+            epilogue_issue_loads16<BITS2 ? 2 : 4>(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);
         }
     };
     auto refill = [&](auto role) __attribute__((always_inline)) {          // every stage of this wave's ring requested
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             asm volatile("" : "+v"(ticket));
             if (tid == 0) *mailbox = dyn_checked(ticket_id(ticket));
         }
-        epilogue_issue_later_words16(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);    // (they land under the first block's tests)
+        epilogue_issue_later_words16<BITS2 ? 2 : 4>(pre, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t);    // (they land under the first block's tests)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (bare: __syncthreads() would also wait for outstanding requests)
         unsigned long long *st = (epi.stamps && wave == 0 && tile_seq < 64) ? epi.stamps + ((int64_t)blockIdx.x * 64 + tile_seq) * 8 : nullptr;
         // the ring refill for the next output tile rides on the epilogue: a quarter of this wave's requests in front of each
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(256, 1) void screen_tile16_kernel(const __bf16 *__r
             };
             if (row_loader) part(std::true_type{}); else part(std::false_type{});
         };
-        fused_epilogue16<kS16Queue>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
+        fused_epilogue16<kS16Queue, decltype(refill_part), BITS2 ? 2 : 4>(acc_token, b0 + wr * 128, n0 + wc * 128, B, n_rows, ep, lane_t, queue, 256, salt, st, pre, qf_lds + wr * 128, refill_part);
     }
 #undef ORR_RD
 #undef ORR_SB
@@ -1479,22 +1480,24 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
     // of the tile; below, the eight-wave form (HBM-bound there, and its two waves per SIMD hide the epilogue's latencies).
     // Measured, 1M x 3072 rows: 128 queries 0.756 -> 0.619 ms, 256: 0.862 -> 0.842, 1024: 3.42 -> 3.30; 64: 0.485 vs 0.506.
     if (B > 64 && D / 64 >= kS4NB) {
-#define ORR_LAUNCH_I8W16(NT) do { \
-        const hipError_t attr = ensure_max_dynamic_lds<screen_tile16_kernel<NT>>(kS4Lds); \
+#define ORR_LAUNCH_I8W16(NT) do { if (epi.count_bits == 2) ORR_LAUNCH_I8W16B(NT, true); else ORR_LAUNCH_I8W16B(NT, false); } while (0)
+#define ORR_LAUNCH_I8W16B(NT, B2) do { \
+        const hipError_t attr = ensure_max_dynamic_lds<screen_tile16_kernel<NT, false, B2>>(kS4Lds); \
         if (attr != hipSuccess) return attr; \
-        hipLaunchKernelGGL((screen_tile16_kernel<NT>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
+        hipLaunchKernelGGL((screen_tile16_kernel<NT, false, B2>), dim3((unsigned)screen_grid(blocks, D / 64)), dim3(256), kS4Lds, s, \
                            static_cast<const __bf16 *>(q_tiled), B, static_cast<const __bf16 *>(e_tiled), row_first, n_rows, D, \
                            static_cast<float *>(nullptr), (int64_t)0, (int32_t)n_ntiles, n_mtiles, flags, epi_use); } while (0)
         // 129+ queries: the tile on 16 x 16 x 64 MFMAs, unless the shard is so large that its epilogue's 32-bit word offsets
         // inside a pair of count planes would not do (then the 32 x 32 x 32 form).  Measured on one box, eight-wave form long
         // gone: 1M x 3072 rows x 256 queries 0.89 -> 0.85 ms, x 1024: 3.23 -> 2.92 ms; C3 (4 launches) 2.23 -> 2.13 ms each.
-        const bool tile16 = (int64_t)((B + 31) / 32) * epi.plane_stride + n_rows < ((int64_t)1 << 30) && n_rows < ((int64_t)1 << 28) && D / 64 > kS4NB &&
-                            epi.qf16 != nullptr;
+        const bool tile16 = screen_i8_uses_tile16(B, n_rows, D, epi.plane_stride) && epi.qf16 != nullptr;
+        if (epi.count_bits == 2 && !tile16) return hipErrorInvalidValue;   // (only the 16 x 16 x 64 form reads two-bit count words)
         if (tile16 && B > 256) ORR_LAUNCH_I8W16(false);
         else if (tile16 && B > 128) ORR_LAUNCH_I8W16(true);
         else if (B > 256) ORR_LAUNCH_I8W4(8, false);
         else if (B > 128) ORR_LAUNCH_I8W4(8, true);
         else ORR_LAUNCH_I8W4(4, true);
+#undef ORR_LAUNCH_I8W16B
 #undef ORR_LAUNCH_I8W16
     }
     else if (B > 128) ORR_LAUNCH_I8(8);
@@ -1510,6 +1513,12 @@ hipError_t launch_screen_i8(const void *q_tiled, int32_t B, const void *e_tiled,
         }
     }
     return hipGetLastError();
+}
+
+bool screen_i8_uses_tile16(int32_t B, int64_t n_rows, int32_t D, int64_t plane_stride)
+{
+    return B > 128 && D > 0 && D % 128 == 0 && D / 64 > kS4NB && (int64_t)((B + 31) / 32) * plane_stride + n_rows < ((int64_t)1 << 30) &&
+           n_rows < ((int64_t)1 << 28);
 }
 
 hipError_t launch_screen_i8_dots(const void *q_tiled, int32_t B, const void *e_tiled, int64_t n_rows, int32_t D, float *S,
