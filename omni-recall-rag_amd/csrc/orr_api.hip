@@ -2373,7 +2373,9 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             idx->pass_cap = kCap;
             const int32_t buf_lists = (int32_t)(kCap / orr::kSelWidth);
             const int32_t lists_total = fused_sample_seg + buf_lists;
-            ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)lists_total * orr::kSelWidth));
+            const int32_t finish_group = orr::finish_survivors_group(B, idx->dim);      // (finish_survivors' lists: one per group)
+            const int32_t lists_room = std::max<int32_t>(lists_total, finish_group ? (int32_t)(kCap / (uint32_t)finish_group) : 0);
+            ORR_TRY(idx->ws_sel.reserve(sizeof(orr::SelEntry) * (size_t)B * (size_t)lists_room * orr::kSelWidth));
             ORR_TRY(idx->ws_tau.reserve(sizeof(unsigned long long) * (size_t)B));
             ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * 3 * (size_t)B));      // [survivors][sampled prefix][workgroups done]
             ORR_TRY(idx->ws_fbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * kCap));

@@ -12,6 +12,8 @@
 #include "orr_epilogue.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <cstdlib>
 
 namespace orr {
@@ -645,14 +647,213 @@ __device__ __forceinline__ double quad_broadcast(double v)
     return __hiloint2double(hi, lo);
 }
 
-template <int S>
-__device__ __forceinline__ double quad_step(double acc, const double (&prod)[64], int c)
+template <int S, int N>
+__device__ __forceinline__ double quad_step(double acc, const double (&prod)[N], int c)
 {
     if (c == S) {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) acc += prod[i];                       // the reference's order: 64 dependent additions
+        for (int i = 0; i < N; ++i) acc += prod[i];                        // the reference's order: N dependent additions
     }
     return quad_broadcast<S>(acc);
+}
+
+// ---- The reference's sum, out of order where that provably changes nothing --------------------------------------------------
+// RecallSearchService.cs:77-82 adds the 3072 products one after the other into a double; re-doing that chain is 3072 dependent
+// additions per survivor (quad_step above).  Rounding is the only thing that makes the order matter, and whether ANY order of a
+// set of terms can round is decidable from two reductions: every product p_j is a float, i.e. an integer multiple of
+// 2^(e_j - 23) (e_j its exponent, -126 for subnormals); with g = min_j (e_j - 23) every sum of every subset of the terms is a
+// multiple of 2^g, and no such sum exceeds M = sum_j |p_j| in magnitude.  A multiple of 2^g below 2^(g + 53) is a double.  So if
+// M < 2^(g + 53), every intermediate sum of EVERY order of additions is exact -- the reference's order included -- and all orders
+// return the same bits: the exact sum.  (A running sum s carried in joins the terms with g_s = the exponent of its lowest set
+// bit and |s| added to M.)  Unit-norm embeddings pass for ~94 % of rows (the products of a row span ~2^25); for the others the
+// row is walked in slabs of 256 columns, each slab tested the same way against the running sum, and a slab that fails is added
+// in the reference's order, one addition after the other (the only place a rounding can happen) -- so the result is the
+// reference's for any input, infinities and NaNs included (their M is not below any limit).
+// mn = min over the terms of (bits of |p| as a float) - 1 (0xFFFFFFFF: every term is zero); M = sum |p| (any order, rounded).
+__device__ __forceinline__ bool any_order_is_exact(double s, double M, uint32_t mn)
+{
+    constexpr int kNone = 1 << 20;
+    int g = kNone;
+    if (mn != 0xFFFFFFFFu) {
+        int field = (int)((mn + 1u) >> 23);
+        field = field < 1 ? 1 : field;
+        g = field - 127 - 23;
+    }
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(s) & 0x7FFFFFFFFFFFFFFFull;
+    if (sb != 0ull) {
+        const int ef = (int)(sb >> 52);
+        const unsigned long long m = (sb & 0xFFFFFFFFFFFFFull) | (ef ? 1ull << 52 : 0ull);
+        const int gs = (ef ? ef : 1) - 1023 - 52 + (m ? __builtin_ctzll(m) : 0);
+        g = gs < g ? gs : g;
+    }
+    if (g == kNone) return true;                                   // nothing but zeros
+    int e = g + 53;
+    if (e > 1023) e = 1023;
+    if (e < -1000) return false;
+    // 2^e (1 - 2^-20): the margin covers the roundings of M itself (a few dozen additions, 2^-53 each)
+    const double lim = __longlong_as_double((long long)((unsigned long long)(e + 1023) << 52)) * 0.99999904632568359375;
+    return __builtin_fabs(s) + M <= lim;                           // (false for NaN and for infinities)
+}
+
+// Three reductions at once (their shuffles overlap): sum, sum, min over the lanes whose index differs in the bits of `mask`
+// (63: the wave; 15: each row of 16 lanes).
+__device__ __forceinline__ void lanes_reduce(double &t, double &a, uint32_t &m, int mask)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        if (!(mask & off)) continue;
+        const double to = __shfl_xor(t, off, 64), ao = __shfl_xor(a, off, 64);
+        const uint32_t mo = (uint32_t)__shfl_xor((int)m, off, 64);
+        t += to;
+        a += ao;
+        m = mo < m ? mo : m;
+    }
+}
+
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    // (lanes add in different orders: identical when the sums are exact, and made identical for the comparison otherwise)
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+__device__ __forceinline__ double lane_f64(double v, int lane_index)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_index), __builtin_amdgcn_readlane(__double2loint(v), lane_index));
+}
+
+// One wave, one row; lane l holds columns [256 k + 4 l, +4) of slab k (coalesced 1 KB loads), the query's D floats are in LDS.
+// CH slabs of a row are in registers at a time (CH divides D / 256: 12 = a whole row of 3072; no predicates, so the loads of the
+// next chunk stay in flight behind counted waits while this one is added).
+template <int CH>
+__device__ __forceinline__ void load_chunk(float4 (&dst)[CH], const float *row, int chunk, int lane)
+{
+    const float4 *r4 = reinterpret_cast<const float4 *>(row) + lane + (int64_t)chunk * (CH * 64);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) dst[u] = r4[u * 64];
+}
+
+// T: this lane's sum (double, additions in any order), M: its sum of magnitudes in fp32 (rounded: the caller widens the limit by
+// 2^-16), mn2: min over its nonzero products of (bits << 1) - 1.
+template <int CH>
+__device__ __forceinline__ void add_chunk(const float4 (&cur)[CH], const float *q_lds, int chunk, int lane, double &T, float &M,
+                                          uint32_t &mn2)
+{
+    const float4 *q4 = reinterpret_cast<const float4 *>(q_lds) + lane + chunk * (CH * 64);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        const float4 qv = q4[u * 64];
+        const float p0 = qv.x * cur[u].x, p1 = qv.y * cur[u].y, p2 = qv.z * cur[u].z, p3 = qv.w * cur[u].w;
+        T += (double)p0; T += (double)p1; T += (double)p2; T += (double)p3;
+        M += __builtin_fabsf(p0); M += __builtin_fabsf(p1); M += __builtin_fabsf(p2); M += __builtin_fabsf(p3);
+        const uint32_t b0 = (__float_as_uint(p0) << 1) - 1u, b1 = (__float_as_uint(p1) << 1) - 1u;
+        const uint32_t b2 = (__float_as_uint(p2) << 1) - 1u, b3 = (__float_as_uint(p3) << 1) - 1u;
+        const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3, m4 = m01 < m23 ? m01 : m23;
+        mn2 = m4 < mn2 ? m4 : mn2;
+    }
+}
+
+// Sum / min over the wave with DPP rotations inside each row of 16 lanes, the four rows joined through scalar registers; every
+// lane gets the result.
+template <int ROR>
+__device__ __forceinline__ uint32_t row_ror_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + ROR, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ double wave_total_f64(double v)
+{
+#define ORR_STEP(R)                                                                                              \
+    v += __hiloint2double((int)row_ror_u32<R>((uint32_t)__double2hiint(v)), (int)row_ror_u32<R>((uint32_t)__double2loint(v)))
+    ORR_STEP(8); ORR_STEP(4); ORR_STEP(2); ORR_STEP(1);
+#undef ORR_STEP
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+
+__device__ __forceinline__ float wave_total_f32(float v)
+{
+    v += __uint_as_float(row_ror_u32<8>(__float_as_uint(v)));
+    v += __uint_as_float(row_ror_u32<4>(__float_as_uint(v)));
+    v += __uint_as_float(row_ror_u32<2>(__float_as_uint(v)));
+    v += __uint_as_float(row_ror_u32<1>(__float_as_uint(v)));
+    const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+    const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    const float c = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    const float d = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 48));
+    return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    uint32_t o;
+    o = row_ror_u32<8>(v); v = o < v ? o : v;
+    o = row_ror_u32<4>(v); v = o < v ? o : v;
+    o = row_ror_u32<2>(v); v = o < v ? o : v;
+    o = row_ror_u32<1>(v); v = o < v ? o : v;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// The rows that do not pass as a whole: slab by slab (256 columns) against the running sum, a slab that does not pass in four
+// blocks of 64 columns (the lanes of one row of 16), a block that does not pass in the reference's order, one addition after
+// the other (the products handed over by readlane) -- the only place a rounding can happen.  CH slabs are loaded at a time.
+// Every lane returns the same value.
+template <int CH>
+__device__ __noinline__ double exact_dot_by_slabs(const float *__restrict__ row, const float *q_lds, int32_t D, int lane)
+{
+    const int chunks = (D >> 8) / CH;
+    const float4 *q4 = reinterpret_cast<const float4 *>(q_lds) + lane;
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        float4 cv[CH];
+        load_chunk<CH>(cv, row, c, lane);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const float4 qv = q4[(c * CH + u) * 64];
+            const float p0 = qv.x * cv[u].x, p1 = qv.y * cv[u].y, p2 = qv.z * cv[u].z, p3 = qv.w * cv[u].w;
+            const double d0 = (double)p0, d1 = (double)p1, d2 = (double)p2, d3 = (double)p3;
+            double t = 0.0;
+            t += d0; t += d1; t += d2; t += d3;
+            double a = __builtin_fabs(d0);
+            a += __builtin_fabs(d1); a += __builtin_fabs(d2); a += __builtin_fabs(d3);
+            const uint32_t b0 = (__float_as_uint(p0) & 0x7FFFFFFFu) - 1u, b1 = (__float_as_uint(p1) & 0x7FFFFFFFu) - 1u;
+            const uint32_t b2 = (__float_as_uint(p2) & 0x7FFFFFFFu) - 1u, b3 = (__float_as_uint(p3) & 0x7FFFFFFFu) - 1u;
+            const uint32_t m01 = b0 < b1 ? b0 : b1, m23 = b2 < b3 ? b2 : b3;
+            uint32_t m = m01 < m23 ? m01 : m23;
+            lanes_reduce(t, a, m, 15);                             // per block of 64 columns
+            double tb[4], ab[4];
+            uint32_t mb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tb[q] = lane_f64(t, 16 * q);
+                ab[q] = lane_f64(a, 16 * q);
+                mb[q] = (uint32_t)__builtin_amdgcn_readlane((int)m, 16 * q);
+            }
+            const double ts = (tb[0] + tb[1]) + (tb[2] + tb[3]), as = (ab[0] + ab[1]) + (ab[2] + ab[3]);
+            const uint32_t m0 = mb[0] < mb[1] ? mb[0] : mb[1], m1 = mb[2] < mb[3] ? mb[2] : mb[3], ms = m0 < m1 ? m0 : m1;
+            if (any_order_is_exact(s, as, ms)) {
+                s += ts;                                           // exact, like every step of the reference's 256 additions
+                continue;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (any_order_is_exact(s, ab[q], mb[q])) {
+                    s += tb[q];
+                    continue;
+                }
+                // the reference's order (every lane runs the same chain: the value stays wave-uniform)
+#pragma unroll
+                for (int l = 0; l < 16; ++l) {
+                    s += lane_f64(d0, 16 * q + l);
+                    s += lane_f64(d1, 16 * q + l);
+                    s += lane_f64(d2, 16 * q + l);
+                    s += lane_f64(d3, 16 * q + l);
+                }
+            }
+        }
+    }
+    return s;
 }
 
 // The whole tail of a two-stage pass in ONE launch (up to 256 queries; each launch boundary on this chain costs a
@@ -663,6 +864,12 @@ __device__ __forceinline__ double quad_step(double acc, const double (&prod)[64]
 //      tree through LDS), writes the k' records and the trailer (what select_final_kernel writes), and copies the
 //      records' exact dots out of the buffer (records_dot_from_buffer_kernel).
 // recs may be pinned host memory (the records are final when written); cnt_host (optional, pinned) receives cnt[b].
+// NJ = float4s a lane holds per round: 16 (a quad walks 256 columns a round: 310 registers, one wave per SIMD -- the rhythm
+// that hides a one-query call's load latency behind the chain) or 8 (128 columns: under 170 registers, three waves per SIMD --
+// for large batches, whose survivors are more waves than the chip has SIMDs).
+// WG = 0: the quad chain above, groups of 64 survivors.  WG = 64 ... 4: one WAVE per survivor (sums out of order, above), groups
+// of WG survivors (small groups spread a small batch's survivors over the chip; lists then hold WG entries of their 64).
+template <int WG, int CH, int NJ, int AH, bool QLDS>
 __global__ __launch_bounds__(256) void finish_survivors_kernel(const float *__restrict__ E, int32_t D, const float *__restrict__ Q,
                                                                const double *__restrict__ norm_b, const int64_t *__restrict__ created,
                                                                const int64_t *__restrict__ row_ids, KwView kw,
@@ -671,62 +878,165 @@ __global__ __launch_bounds__(256) void finish_survivors_kernel(const float *__re
                                                                SelEntry *__restrict__ buf, double *__restrict__ buf_dot,
                                                                SelEntry *__restrict__ lists, int32_t kprime, int64_t n_rows,
                                                                int64_t row_base, const double *__restrict__ two_stage_L,
-                                                               orr_candidate *__restrict__ recs, uint32_t *__restrict__ cnt_host)
+                                                               orr_candidate *__restrict__ recs, uint32_t *__restrict__ cnt_host,
+                                                               unsigned long long *__restrict__ stamps, int phase)
 {
+    // phase 0: all of the above in this launch.  Large batches split it at the tickets (phase 1: the groups, every list
+    // written; phase 2: one workgroup per query merges and writes the records): the launch boundary orders the two halves,
+    // where the one-launch form pays a device-wide fence per group and one per query (L2 write-backs across the XCDs) --
+    // tens of us per workgroup by the stamps, against a few us between two launches.
+#define ORR_FSTAMP(k) if (stamps && tid == 0) stamps[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
     __shared__ SelEntry sh[4][kSelWidth];
     __shared__ uint32_t want[kSelWidth];
     __shared__ uint32_t ticket;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, c = lane & 3, r16 = lane >> 2;
     const uint32_t total = cnt[b];
     const uint32_t n = total < cap ? total : cap;
-    const uint32_t active = n ? (n + 63u) / 64u : 1u;          // a query without survivors still gets its (empty) records
-    if (blockIdx.y >= active) return;
-    const uint32_t first = blockIdx.y * 64u;
-    const int64_t n_lists = cap / 64u;
+    constexpr uint32_t G = WG ? WG : 64;                        // survivors per group
+    const uint32_t active = n ? (n + G - 1u) / G : 1u;          // a query without survivors still gets its (empty) records
+    if (blockIdx.y >= (phase == 2 ? 1u : active)) return;
+    ORR_FSTAMP(0);
+    extern __shared__ __attribute__((aligned(16))) float q_lds[];  // QLDS / WG: the query's D floats, staged once per workgroup
+    if ((QLDS || WG) && n && phase != 2) {
+        for (int i = tid * 4; i < D; i += 1024)
+            *reinterpret_cast<float4 *>(q_lds + i) = *reinterpret_cast<const float4 *>(Q + (int64_t)b * D + i);
+        __syncthreads();
+    }
+    const int64_t n_lists = cap / G;
     unsigned long long k = 0ull;                                   // this wave's running best 64 (finisher)
     uint32_t p = 0xFFFFFFFFu;
-    if (n) {
+    // (a workgroup walks the query's groups of 64 survivors y, y + gridDim.y, ...: the grid is a few workgroups per query, not
+    // cap / 64 of which nearly all would exit at once -- 32,768 launches for 256 queries with the default buffers)
+    bool finisher = false;
+    for (uint32_t yb = blockIdx.y; yb < active && !finisher && phase != 2; yb += gridDim.y) {
+    const uint32_t first = yb * G;
+    k = 0ull;
+    p = 0xFFFFFFFFu;
+    if (WG && n) {
+        // ---- one wave per survivor, G / 4 survivors per wave; the next survivor's row (and what its score needs) is fetched
+        // while this one's is added
+        constexpr int kPerWave = (int)G / 4;
+        if (G < 64u && wave == 0 && lane >= (int)G) { sh[0][lane].key = 0ull; sh[0][lane].pos = 0xFFFFFFFFu; }
+        const QueryConst qc0 = qcs[b];
+        const int chunks = (D >> 8) / CH;
+        const uint32_t wave_first = first + (uint32_t)(wave * kPerWave);
+        const int live = wave_first < n ? (int)(n - wave_first < (uint32_t)kPerWave ? n - wave_first : (uint32_t)kPerWave) : 0;
+        SelEntry *mine = buf + (int64_t)b * cap + wave_first;
+        // lane i: the row of this wave's i-th survivor and what its score needs besides the dot (one round of dependent loads
+        // for all of them, before the rows; readlane hands them out)
+        const bool mine_live = lane < live;
+        const uint32_t my_pos = mine_live ? mine[lane].pos : 0u;
+        const double my_nb = mine_live ? norm_b[my_pos] : 0.0;
+        const int64_t my_cr = mine_live ? created[my_pos] : 0;
+        const uint32_t my_m = (mine_live && qc0.n_terms > 0) ? kw_matches(kw, b, my_pos) : 0u;
+        ORR_FSTAMP(1);
+        float4 buf_a[CH], buf_b[CH];                                  // this chunk and the next, swapping roles (no copies: a
+                                                                      // copy would wait for the next chunk's loads)
+        if (live > 0) load_chunk<CH>(buf_a, E + (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_pos, 0) * (int64_t)D, 0, lane);
+        double T = 0.0;                                              // (+0.0: the reference's sum starts there and can never be -0)
+        float M = 0.0f;
+        uint32_t mn2 = 0xFFFFFFFFu;
+        double row_T = 0.0;                                          // lane i: what the wave found for its i-th survivor
+        float row_M = 0.0f;
+        uint32_t row_mn2 = 0xFFFFFFFFu;
+        int i = 0, ch = 0;
+        auto step = [&](const float4 (&cur)[CH], float4 (&nxt)[CH]) {
+            const int nch = ch + 1 == chunks ? 0 : ch + 1, ni = nch ? i : i + 1;
+            // the next chunk, unconditionally (behind the last one: that one again) -- a branch here would make every wait
+            // below a wait for these loads as well
+            const int ni_c = ni < live ? ni : live - 1;
+            const int64_t row_nxt = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_pos, ni_c);
+            load_chunk<CH>(nxt, E + row_nxt * (int64_t)D, nch, lane);
+            add_chunk<CH>(cur, q_lds, ch, lane, T, M, mn2);
+            if (nch == 0) {                                          // the row is complete: its totals go to lane i
+                const double t = wave_total_f64(T);
+                const float a = wave_total_f32(M);
+                const uint32_t m = wave_min_u32(mn2);
+                if (lane == i) { row_T = t; row_M = a; row_mn2 = m; }
+                T = 0.0; M = 0.0f; mn2 = 0xFFFFFFFFu;
+            }
+            i = ni;
+            ch = nch;
+        };
+        while (i < live) {
+            step(buf_a, buf_b);
+            if (i >= live) break;
+            step(buf_b, buf_a);
+        }
+        ORR_FSTAMP(2);
+        // ---- lane i finishes survivor i: rows whose sum may depend on the order are added again, the reference's way
+        const uint32_t row_mn = ((row_mn2 + 1u) >> 1) - 1u;          // (bits << 1) - 1  ->  bits - 1
+        const bool any_order = any_order_is_exact(0.0, (double)row_M * 1.0000152587890625, row_mn);    // (1 + 2^-16: M's fp32 roundings)
+        unsigned long long redo = __ballot(mine_live && !any_order);
+        while (redo) {
+            const int r = __builtin_ctzll(redo);
+            redo &= redo - 1ull;
+            const int64_t row_r = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_pos, r);
+            const double acc_r = exact_dot_by_slabs<CH>(E + row_r * (int64_t)D, q_lds, D, lane);
+            if (lane == r) row_T = acc_r;
+        }
+        ORR_FSTAMP(3);
+        if (mine_live) {
+            QueryConst exact = qc0;
+            exact.use_cos = 1;                                       // this path only runs with cosine; guards are inside fused_score
+            const unsigned long long key = score_key(fused_score(row_T, my_nb, my_cr, my_m, exact, now_ticks));
+            mine[lane].key = key;
+            mine[lane].pad = my_m;                                   // the record's matches (below)
+            buf_dot[(int64_t)b * cap + wave_first + lane] = row_T;   // ... and its exact dot
+            sh[0][wave * kPerWave + lane].key = key;
+            sh[0][wave * kPerWave + lane].pos = my_pos;
+        }
+        if (lane >= live && lane < kPerWave) { sh[0][wave * kPerWave + lane].key = 0ull; sh[0][wave * kPerWave + lane].pos = 0xFFFFFFFFu; }
+    } else if (n) {
         SelEntry *mine = buf + (int64_t)b * cap + first + wave * 16;
         const bool live = first + wave * 16 + r16 < n;
         unsigned long long key = 0ull;
         uint32_t pos = 0xFFFFFFFFu;
         if (first + wave * 16 < n) {                            // (whole waves beyond the last survivor skip the dot)
             const int64_t my_row = live ? (int64_t)mine[r16].pos : 0;          // quads without a survivor read row 0 and are ignored
-            const float *src = E + my_row * (int64_t)D + c * 64;
-            const float *qsrc = Q + (int64_t)b * D + c * 64;
-            float4 cur[16], qc[16];
+            constexpr int kCols = NJ * 16;                                     // columns a quad walks per round
+            const float *src = E + my_row * (int64_t)D + c * (NJ * 4);
+            const float *qsrc = Q + (int64_t)b * D + c * (NJ * 4);
+            float4 cur[AH][NJ], qc[QLDS ? 1 : AH][NJ];                       // AH rounds of the row in flight
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                cur[j] = *reinterpret_cast<const float4 *>(src + j * 4);
-                qc[j] = *reinterpret_cast<const float4 *>(qsrc + j * 4);
-            }
+            for (int u = 0; u < AH; ++u)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    cur[u][j] = *reinterpret_cast<const float4 *>(src + u * kCols + j * 4);
+                    if (!QLDS) qc[u][j] = *reinterpret_cast<const float4 *>(qsrc + u * kCols + j * 4);
+                }
             // what the score needs besides the dot, fetched before the 3072-step chain instead of behind it
             const QueryConst qc0 = qcs[b];
             const double nb_row = norm_b[my_row];
             const int64_t cr_row = created[my_row];
             const uint32_t m = (qc0.n_terms > 0 && live && c == 0) ? kw_matches(kw, b, (uint32_t)my_row) : 0u;
             double acc = 0.0;
-            for (int c0 = 0; c0 < D; c0 += 256) {
-                // the products are not part of the chain: all four lanes of the quad round and widen theirs at once
-                double prod[64];
+            for (int c0 = 0; c0 < D; c0 += kCols * AH) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float p0 = qc[j].x * cur[j].x;
-                    float p1 = qc[j].y * cur[j].y;
-                    float p2 = qc[j].z * cur[j].z;
-                    float p3 = qc[j].w * cur[j].w;
-                    prod[4 * j + 0] = (double)p0; prod[4 * j + 1] = (double)p1; prod[4 * j + 2] = (double)p2; prod[4 * j + 3] = (double)p3;
-                }
-                const int cn = c0 + 256 < D ? c0 + 256 : c0;                  // clamped, never branched around
+                for (int u = 0; u < AH; ++u) {
+                    const int col = c0 + u * kCols;
+                    // the products are not part of the chain: all four lanes of the quad round and widen theirs at once
+                    double prod[NJ * 4];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    cur[j] = *reinterpret_cast<const float4 *>(src + cn + j * 4);
-                    qc[j] = *reinterpret_cast<const float4 *>(qsrc + cn + j * 4);
+                    for (int j = 0; j < NJ; ++j) {
+                        const float4 qv = QLDS ? *reinterpret_cast<const float4 *>(q_lds + col + c * (NJ * 4) + j * 4) : qc[QLDS ? 0 : u][j];
+                        float p0 = qv.x * cur[u][j].x;
+                        float p1 = qv.y * cur[u][j].y;
+                        float p2 = qv.z * cur[u][j].z;
+                        float p3 = qv.w * cur[u][j].w;
+                        prod[4 * j + 0] = (double)p0; prod[4 * j + 1] = (double)p1; prod[4 * j + 2] = (double)p2; prod[4 * j + 3] = (double)p3;
+                    }
+                    const int cn = col + kCols * AH < D ? col + kCols * AH : col;   // clamped, never branched around
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        cur[u][j] = *reinterpret_cast<const float4 *>(src + cn + j * 4);
+                        if (!QLDS) qc[u][j] = *reinterpret_cast<const float4 *>(qsrc + cn + j * 4);
+                    }
+                    acc = quad_step<0>(acc, prod, c);
+                    acc = quad_step<1>(acc, prod, c);
+                    acc = quad_step<2>(acc, prod, c);
+                    acc = quad_step<3>(acc, prod, c);
                 }
-                acc = quad_step<0>(acc, prod, c);
-                acc = quad_step<1>(acc, prod, c);
-                acc = quad_step<2>(acc, prod, c);
-                acc = quad_step<3>(acc, prod, c);
             }
             if (live && c == 0) {
                 QueryConst exact = qc0;
@@ -739,27 +1049,41 @@ __global__ __launch_bounds__(256) void finish_survivors_kernel(const float *__re
             }
         }
         if (c == 0) { sh[0][wave * 16 + r16].key = key; sh[0][wave * 16 + r16].pos = pos; }
+    }
+    ORR_FSTAMP(4);
+    if (n) {
         __syncthreads();
         if (wave == 0) {
             k = sh[0][lane].key;
             p = sh[0][lane].pos;
             wave_sort(k, p, lane);
-            if (active > 1u) {
+            if (active > 1u || phase == 1) {
                 SelEntry o;
                 o.key = k; o.pos = p; o.pad = 0;
-                lists[((int64_t)b * n_lists + blockIdx.y) * kSelWidth + lane] = o;
+                lists[((int64_t)b * n_lists + yb) * kSelWidth + lane] = o;
             }
         }
     }
-    if (active > 1u) {
-        // ---- the last workgroup of the query finishes it (every thread's writes are visible device-wide before the ticket);
-        // a query with at most 64 survivors is finished by its only workgroup from the list it holds
+    if (phase == 1) {
+        __syncthreads();                                           // (sh[0] is rewritten by the next group)
+    } else if (active > 1u) {
+        // ---- the workgroup that finishes the query's LAST group of survivors finishes the query (every thread's writes are
+        // visible device-wide before the ticket); a query with at most 64 survivors is finished by its only workgroup from the
+        // list it holds
         __threadfence();
         __syncthreads();
         if (tid == 0) ticket = atomicAdd(&done[b], 1u);
         __syncthreads();
-        if (ticket != active - 1u) return;
-        __threadfence();
+        finisher = ticket == active - 1u;
+        __syncthreads();                                           // (`ticket` is rewritten by the next group)
+    } else {
+        finisher = true;
+    }
+    }
+    ORR_FSTAMP(5);
+    if (phase == 1 || (!finisher && phase == 0)) return;
+    if (active > 1u || (phase == 2 && n)) {
+        if (phase == 0) __threadfence();
         k = 0ull;
         p = 0xFFFFFFFFu;
         for (uint32_t l = (uint32_t)wave; l < active; l += 4u) {
@@ -810,6 +1134,8 @@ __global__ __launch_bounds__(256) void finish_survivors_kernel(const float *__re
                 o[r].flags = ORR_CAND_DOT_EXACT;
             }
     }
+    ORR_FSTAMP(6);
+#undef ORR_FSTAMP
 }
 
 hipError_t launch_finish_survivors(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b, const int64_t *created,
@@ -820,9 +1146,73 @@ hipError_t launch_finish_survivors(const float *E, int32_t D, const float *Q, in
 {
     if (B <= 0) return hipSuccess;
     if (D % 256 != 0 || cap % 64 != 0 || kprime < 1 || kprime > kSelWidth || !two_stage_L) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(finish_survivors_kernel, dim3((unsigned)B, cap / 64), dim3(256), 0, s, E, D, Q, norm_b, created, row_ids, kw, qc,
-                       now_ticks, cnt, done, cap, buf, buf_dot, lists, kprime, n_rows, row_base, two_stage_L, recs, cnt_host);
+    // (a few workgroups per query, each walking the query's groups of survivors; more for small batches, whose few queries
+    // would otherwise leave the chip empty)
+    const int32_t group = finish_survivors_group(B, D);
+    unsigned per_query = std::min<unsigned>(cap / (group ? group : 64), B >= 128 ? 4u : B >= 16 ? 16u : 64u);
+#define ORR_LAUNCH_FINISH(WG, CH, LDS_BYTES)                                                                                          \
+    hipLaunchKernelGGL((finish_survivors_kernel<WG, CH, 4, 2, false>), dim3((unsigned)B, per_query), dim3(256), LDS_BYTES, s, E, D, Q, \
+                       norm_b, created, row_ids, kw, qc, now_ticks, cnt, done, cap, buf, buf_dot, lists, kprime, n_rows, row_base,      \
+                       two_stage_L, recs, cnt_host, stamps_arg, phase)
+#define ORR_LAUNCH_FINISH_WAVES(WG)                                                                                                    \
+    do {                                                                                                                                \
+        if (slabs % 12 == 0) ORR_LAUNCH_FINISH(WG, 12, wave_lds);                                                                       \
+        else if (slabs % 4 == 0) ORR_LAUNCH_FINISH(WG, 4, wave_lds);                                                                    \
+        else if (slabs % 3 == 0) ORR_LAUNCH_FINISH(WG, 3, wave_lds);                                                                    \
+        else ORR_LAUNCH_FINISH(WG, 1, wave_lds);                                                                                        \
+    } while (0)
+    // ORR_FINISH_STAMPS=file (diagnostic): every launch appends its workgroups' phase stamps (100 MHz) to the file
+    static const char *stamps_path = getenv("ORR_FINISH_STAMPS");
+    unsigned long long *d_stamps = nullptr;
+    const size_t stamp_words = (size_t)B * (per_query + 1) * 8;      // (the second launch of a split one stamps behind the first)
+    if (stamps_path) {
+        if (hipMalloc(reinterpret_cast<void **>(&d_stamps), stamp_words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_stamps, 0, stamp_words * 8, s);
+    }
+    const size_t wave_lds = (size_t)D * 4;                                     // the query
+    const int slabs = D / 256;
+    // one launch (tickets) for small batches, whose call pays every launch boundary; two for large ones (ORR_FINISH_SPLIT=0|1
+    // forces either)
+    static const int forced_split = [] { const char *e = getenv("ORR_FINISH_SPLIT"); return e ? atoi(e) : -1; }();
+    const bool split = forced_split >= 0 ? forced_split != 0 : B >= 64;
+    for (int phase = split ? 1 : 0; phase <= (split ? 2 : 0); ++phase) {
+        unsigned long long *stamps_arg = d_stamps ? d_stamps + (phase == 2 ? (size_t)B * per_query * 8 : 0) : nullptr;
+        if (phase == 2) per_query = 1;
+        if (group == 16) ORR_LAUNCH_FINISH_WAVES(16);
+        else if (group == 4) ORR_LAUNCH_FINISH_WAVES(4);
+        else ORR_LAUNCH_FINISH(0, 1, 0);
+    }
+#undef ORR_LAUNCH_FINISH_WAVES
+    if (d_stamps) {
+        std::vector<unsigned long long> h(stamp_words);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), d_stamps, stamp_words * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(stamps_path, "a")) {
+                fprintf(f, "launch B=%d per_query=%u group=%d\n", B, per_query, group);
+                for (size_t w = 0; w < stamp_words; w += 8)
+                    if (h[w]) fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu\n", w / 8, h[w], h[w + 1], h[w + 2], h[w + 3], h[w + 4], h[w + 5], h[w + 6]);
+                fclose(f);
+            }
+        }
+        (void)hipFree(d_stamps);
+    }
+#undef ORR_LAUNCH_FINISH
     return hipGetLastError();
+}
+
+// Survivors per group of finish_survivors for a batch of B (its lists: cap / group per query, kSelWidth entries each); 0: the quad
+// chain (groups of 64).  One wave per survivor for the smallest batches only (1M x 3072 rows, one MI355X, us per launch):
+//     queries   1    8    32   64   256 (10M rows)
+//     chain     31   35   40   41   103      (two launches from 64 queries on; 220 in one)
+//     waves     23   32   47   87   162-234  (groups of 4 / 4 / 16 / 16 / 16-64)
+// -- with many survivors per wave the rows that are added twice (6 % of them, 10-30 us each) are a tail the chain does not have.
+// ORR_FINISH_CHAIN=1 forces the chain, ORR_FINISH_GROUP=16|4 the group (experiments).
+int32_t finish_survivors_group(int32_t B, int32_t D)
+{
+    static const bool chain = [] { const char *e = getenv("ORR_FINISH_CHAIN"); return e && atoi(e) != 0; }();
+    static const int forced = [] { const char *e = getenv("ORR_FINISH_GROUP"); return e ? atoi(e) : 0; }();
+    if (chain || D > 8192) return 0;
+    if (forced == 16 || forced == 4) return forced;
+    return B < 8 ? 4 : 0;
 }
 
 hipError_t launch_rescore_buffer_exact(const float *E, int32_t D, const float *Q, int32_t B, const double *norm_b,

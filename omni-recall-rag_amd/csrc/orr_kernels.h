@@ -286,6 +286,8 @@ hipError_t launch_finish_survivors(const float *E, int32_t D, const float *Q, in
                                    uint32_t *done, uint32_t cap, SelEntry *buf, double *buf_dot, SelEntry *lists, int32_t kprime,
                                    int64_t n_rows, int64_t row_base, const double *two_stage_L, orr_candidate *recs, uint32_t *cnt_host,
                                    hipStream_t s);
+// survivors per group of that launch (its `lists`: B x cap / group x kSelWidth entries); 0 = groups of 64
+int32_t finish_survivors_group(int32_t B, int32_t D);
 hipError_t launch_records_dot_from_buffer(const SelEntry *buf, const double *buf_dot, const uint32_t *cnt, uint32_t cap, int32_t B,
                                           int32_t kprime, int64_t row_base, orr_candidate *recs, hipStream_t s);
 hipError_t launch_buffer_to_lists(const SelEntry *buf, const uint32_t *cnt, uint32_t cap, int32_t B, int32_t seg_first,
