@@ -2387,7 +2387,9 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 HIP_TRY(orr::launch_fuse_select(nullptr, d_dotf, dotf_rows, idx->d_norm_b,
                                                 idx->d_created, d_rowc, kw, idx->ws_qc.as<orr::QueryConst>(), a.now_ticks,
                                                 std::min<int64_t>(dotf_rows, n), B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
-                                                lists_total, s, i8p));
+                                                lists_total, s, i8p,
+                                                // two-stage: the prefix only yields the floor (the records come out of the survivors' buffers)
+                                                two_stage && d_rowc != nullptr && !getenv("ORR_PREFIX_FULL_RANKING")));
             }
             ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * 2 * (size_t)B));
             orr::FusedEpilogue epi{};

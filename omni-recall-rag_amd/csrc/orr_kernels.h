@@ -181,7 +181,8 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
-                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8 = I8Prefix());
+                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8 = I8Prefix(),
+                              bool floor_only = false);     // floor_only: lists of per-lane maxima (enough for a floor key; FAST rows, no tau)
 
 // K5b: merges the per-workgroup lists of each query and writes kprime candidate
 // records plus the trailer ([B][kprime+1], see orr_candidate).
