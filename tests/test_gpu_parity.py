@@ -656,8 +656,8 @@ def test_two_stage_pass_at_a_dimension_that_is_a_multiple_of_256():
         rows, scores, counts = idx.search(qs[b0:b0 + nb], terms[b0:b0 + nb], NOW, 10, candidate_limit=n)
         st = idx.kernel_stats()
         idx.set_profiling(False)
-        # up to 256 queries: the one-launch tail (finish_survivors); beyond, the separate kernels
-        assert ("finish_survivors" if nb <= 256 else "rescore_buffer_exact") in st and "dot_exact" not in st, sorted(st)
+        # dim % 256 == 0: the tail of the pass is finish_survivors (one launch; two from 64 queries on), else the separate kernels
+        assert "finish_survivors" in st and "rescore_buffer_exact" not in st and "dot_exact" not in st, sorted(st)
         for b in sorted({0, min(1, nb - 1), nb - 1}):
             orow, osc, _ = corpus.search(qs[b0 + b], texts[b0 + b], NOW, 10, candidate_limit=n, threads=8)
             assert list(rows[b, :counts[b]]) == list(orow) and np.array_equal(scores[b, :counts[b]], osc), (b0, nb, b)
@@ -676,7 +676,7 @@ def test_two_stage_pass_at_a_dimension_that_is_a_multiple_of_256():
     got = idx.search(q2, terms2, NOW, 10, candidate_limit=n)
     st = idx.kernel_stats()
     idx.set_profiling(False)
-    assert st["screen_i8_fused"]["launches"] == 1 and "gemm_dot_bf16x3" not in st, sorted(st)
+    assert st["screen_i8_fused"]["launches"] == 1 and "gemm_dot_bf16x3" not in st and "finish_survivors" in st, sorted(st)
     assert all(np.array_equal(x, y) for x, y in zip(plain, got))
     assert got[0][255, 0] == 77_777 and got[0][256, 0] == n - 1 and got[0][299, 0] == 123_456
     for b in (0, 255, 256, 299):
