@@ -136,6 +136,12 @@ struct orr_index {
     int64_t row_base = 0;
     hipStream_t stream = nullptr;      // main stream: dots, fused score, selection
     hipStream_t stream_kw = nullptr;   // keyword scan runs beside the HBM-bound dot kernel
+    hipStream_t stream_aux = nullptr;  // what must not sit in front of the keyword chain: the clearing of the term bitmaps behind a
+                                       // search (0.1 ms at 10M rows x 256 queries) and the norms of device-resident queries
+    hipEvent_t ev_bm_clean = nullptr;  // ... recorded behind that clearing; the next search's posting expansion waits for it
+    bool bm_clean_pending = false;
+    bool kw_counters_clean = false;    // the hit counter and the per-term hit counts were zeroed behind the last search
+    const void *kw_counters_of[2] = {nullptr, nullptr};
     hipEvent_t ev_inputs = nullptr, ev_kw_done = nullptr, ev_main_ready = nullptr, ev_range[15] = {};     // (one per row range but the first: 16 ranges at most)
     std::mutex mu;
 
@@ -661,6 +667,8 @@ int orr_index_create(const orr_config *cfg, orr_index **out)
     idx->row_base = cfg->row_base;
     if (hipSetDevice(idx->device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&idx->stream_kw, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&idx->stream_aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&idx->ev_bm_clean, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_inputs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&idx->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
@@ -694,6 +702,9 @@ void orr_index_destroy(orr_index *idx)
     (void)hipSetDevice(idx->device);
     if (idx->stream) (void)hipStreamSynchronize(idx->stream);
     if (idx->stream_kw) (void)hipStreamSynchronize(idx->stream_kw);
+    if (idx->stream_aux) (void)hipStreamSynchronize(idx->stream_aux);
+    if (idx->ev_bm_clean) (void)hipEventDestroy(idx->ev_bm_clean);
+    if (idx->stream_aux) (void)hipStreamDestroy(idx->stream_aux);
     if (idx->ev_inputs) (void)hipEventDestroy(idx->ev_inputs);
     if (idx->ev_kw_done) (void)hipEventDestroy(idx->ev_kw_done);
     if (idx->ev_main_ready) (void)hipEventDestroy(idx->ev_main_ready);
@@ -1542,6 +1553,8 @@ static int make_view(orr_index *parent, orr_index **out, bool internal)
     v->i8_ready = parent->i8_ready; v->i8_failed = !parent->i8_ready;
     if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&v->stream_kw, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_bm_clean, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_inputs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_kw_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_main_ready, hipEventDisableTiming) != hipSuccess ||
@@ -1883,9 +1896,22 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
         hipStream_t k = idx->stream_kw;
         uint8_t *dm = idx->ws_meta.as<uint8_t>();
         HIP_TRY(hipMemcpyAsync(dm, hm, meta_bytes, hipMemcpyHostToDevice, k));
-        if (bm_clean < out.bm_bytes)
-            HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(idx->ws_bitmaps.p) + bm_clean, 0, out.bm_bytes - bm_clean, k));
-        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
+        // (the chain's counters were zeroed behind the last search on this stream, unless this is the first one or they moved)
+        const bool counters_clean = idx->kw_counters_clean && idx->kw_counters_of[0] == idx->ws_counter.p;
+        idx->kw_counters_clean = false;
+        if (!counters_clean) HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), k));
+        bool bitmaps_settled = false;
+        auto settle_bitmaps = [&]() -> int {
+            if (bitmaps_settled) return ORR_OK;
+            bitmaps_settled = true;
+            if (idx->bm_clean_pending) {
+                HIP_TRY(hipStreamWaitEvent(k, idx->ev_bm_clean, 0));
+                idx->bm_clean_pending = false;
+            }
+            if (bm_clean < out.bm_bytes)
+                HIP_TRY(hipMemsetAsync(static_cast<uint8_t *>(idx->ws_bitmaps.p) + bm_clean, 0, out.bm_bytes - bm_clean, k));
+            return ORR_OK;
+        };
         if (V > 0) {
             const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
             {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
@@ -1913,7 +1939,8 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
                 const size_t o_tok = sizeof(uint32_t) * (size_t)TT, o_off = (2 * o_tok + 7) / 8 * 8, o_alias = o_off + sizeof(int64_t) * (size_t)TT;
                 ORR_TRY(idx->ws_kwalias.reserve(o_alias + (size_t)TT + 16));
                 uint8_t *wa = idx->ws_kwalias.as<uint8_t>();
-                HIP_TRY(hipMemsetAsync(wa, 0, o_tok, k));                  // the hit counts
+                if (!(counters_clean && idx->kw_counters_of[1] == idx->ws_kwalias.p))
+                    HIP_TRY(hipMemsetAsync(wa, 0, o_tok, k));              // the hit counts
                 const int64_t delta = (int64_t)(idx->tok_bm.as<uint32_t>() - idx->ws_bitmaps.as<uint32_t>());   // words from the batch's bitmaps to the token store
                 Timed t(idx, "kw_alias", 0.0, k);
                 HIP_TRY(orr::launch_kw_alias(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits, (int32_t)TT,
@@ -1922,6 +1949,9 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
                 out.view.term_word_off = reinterpret_cast<const int64_t *>(wa + o_off);
                 skip = wa + o_alias;
             }
+            // the bitmaps are first written here: the clearing behind the last search (on the auxiliary stream) must be done,
+            // and what lies beyond the cleared part is cleared now
+            ORR_TRY(settle_bitmaps());
             {
                 Timed t(idx, "expand_hits", 0.0, k);
                 HIP_TRY(orr::launch_expand_hits(idx->ws_hits.as<orr::KwHit>(), idx->ws_counter.as<unsigned long long>(), max_hits,
@@ -1929,6 +1959,7 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
                                                 idx->pin_kwcnt.as<unsigned long long>(), skip));     // hits of this pass: statistics
             }
         }
+        ORR_TRY(settle_bitmaps());                     // (a corpus without tokens: nothing expanded, the bitmaps are read all the same)
         HIP_TRY(hipEventRecord(idx->ev_kw_done, k));
         out.view.bitmaps = idx->ws_bitmaps.as<uint32_t>();
         out.view.words_per_term = words;
@@ -2157,8 +2188,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             dev_norms = true;
             ORR_TRY(idx->ws_norm_a.reserve(sizeof(double) * (size_t)B));
             ORR_TRY(idx->pin_norm.reserve(sizeof(double) * (size_t)B));
-            HIP_TRY(orr::launch_dot_exact(d_q, B, a.dim, nullptr, 1, true, idx->ws_norm_a.as<double>(), B, idx->stream_kw));   // beside the first cosine kernel
-            HIP_TRY(hipEventRecord(idx->ev_q, idx->stream_kw));
+            HIP_TRY(orr::launch_dot_exact(d_q, B, a.dim, nullptr, 1, true, idx->ws_norm_a.as<double>(), B, idx->stream_aux));   // beside the first cosine kernel
+            HIP_TRY(hipEventRecord(idx->ev_q, idx->stream_aux));
         } else if (is_device_pointer(a.q)) {
             ORR_TRY(idx->pin_q.reserve(qbytes));
             d_q = a.q;
@@ -2622,8 +2653,21 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     idx->sstats.pass_mode = pass_mode;
     HIP_TRY(hipStreamSynchronize(s));
     if (bm_bytes) {            // every kernel that read the bitmaps is done: clear them for the next search
-        HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, bm_bytes, idx->stream_kw));
+        if (bm_bytes >= ((size_t)16 << 20)) {   // (small ones stay on the keyword stream: a cross-stream wait costs a one-query call more)
+            HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, bm_bytes, idx->stream_aux));
+            HIP_TRY(hipEventRecord(idx->ev_bm_clean, idx->stream_aux));
+            idx->bm_clean_pending = true;
+        } else {
+            HIP_TRY(hipMemsetAsync(idx->ws_bitmaps.p, 0, bm_bytes, idx->stream_kw));
+        }
         idx->bitmaps_clean = std::max(bm_bytes, bm_clean_before);
+    }
+    if (n_terms_total > 0 && idx->ws_counter.p) {   // ... and the keyword chain's counters (two memsets less in front of the next chain)
+        HIP_TRY(hipMemsetAsync(idx->ws_counter.p, 0, sizeof(unsigned long long), idx->stream_kw));
+        if (idx->ws_kwalias.p) HIP_TRY(hipMemsetAsync(idx->ws_kwalias.p, 0, idx->ws_kwalias.cap, idx->stream_kw));
+        idx->kw_counters_clean = true;
+        idx->kw_counters_of[0] = idx->ws_counter.p;
+        idx->kw_counters_of[1] = idx->ws_kwalias.p;
     }
     if (dev_norms) memcpy(idx->h_norm_a.data(), idx->pin_norm.p, sizeof(double) * (size_t)B);
     if (n_terms_total > 0) {
@@ -2641,8 +2685,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     g_ht.mark(4);
     collect_events(idx);
     if (kw_overflow_possible) {
-        unsigned long long cnt = 0;
-        HIP_TRY(hipMemcpy(&cnt, idx->ws_counter.p, sizeof(cnt), hipMemcpyDeviceToHost));
+        // (the counter as expand_hits left it in pinned memory: the device copy is zeroed again behind the pass)
+        const unsigned long long cnt = *idx->pin_kwcnt.as<unsigned long long>();
         const uint32_t hits = (uint32_t)(cnt >> 32);
         if (hits > kw_max_hits) {
             // the distinct terms of this batch match more vocabulary tokens than the hit list holds (short terms against a
