@@ -856,19 +856,20 @@ __device__ __noinline__ double exact_dot_by_slabs(const float *__restrict__ row,
     return s;
 }
 
-// The whole tail of a two-stage pass in ONE launch (up to 256 queries; each launch boundary on this chain costs a
-// one-query search about 10 us of idle GPU): a workgroup of four waves takes 64 survivors of one query,
-//   1. re-scores them as above (16 per wave) and overwrites their keys, dots to buf_dot;
-//   2. sorts its 64 (key, row) pairs into lists[b][y];
+// The whole tail of a two-stage pass (each launch boundary on this chain costs a one-query search about 10 us of idle GPU,
+// so small batches get it in ONE launch): a workgroup of four waves takes groups of survivors of one query,
+//   1. re-scores them (below) and overwrites their keys, dots to buf_dot;
+//   2. sorts the group's (key, row) pairs into lists[b][group];
 //   3. takes a ticket on done[b]; the workgroup that draws the last one merges the query's lists (four waves, then a
 //      tree through LDS), writes the k' records and the trailer (what select_final_kernel writes), and copies the
 //      records' exact dots out of the buffer (records_dot_from_buffer_kernel).
 // recs may be pinned host memory (the records are final when written); cnt_host (optional, pinned) receives cnt[b].
-// NJ = float4s a lane holds per round: 16 (a quad walks 256 columns a round: 310 registers, one wave per SIMD -- the rhythm
-// that hides a one-query call's load latency behind the chain) or 8 (128 columns: under 170 registers, three waves per SIMD --
-// for large batches, whose survivors are more waves than the chip has SIMDs).
-// WG = 0: the quad chain above, groups of 64 survivors.  WG = 64 ... 4: one WAVE per survivor (sums out of order, above), groups
-// of WG survivors (small groups spread a small batch's survivors over the chip; lists then hold WG entries of their 64).
+// WG = 0: four lanes per survivor (quad_step above), groups of 64; NJ float4s per lane and round (a quad walks 16 NJ columns a
+// round), AH rounds of the row in flight, QLDS: the query from LDS instead of registers -- measured from 16 to 256 columns per
+// round, one to eight rounds ahead, both query sources (10M rows x 256 queries 185-255 us, one query 32-49 us): the launch
+// uses 64 columns, two rounds ahead, registers.  WG = 16 / 4: one WAVE per survivor (sums out of order where provably exact,
+// above), groups of WG survivors (small groups spread a small batch's survivors over the chip; lists then hold WG entries of
+// their 64), CH slabs of 256 columns per load (CH divides D / 256).
 template <int WG, int CH, int NJ, int AH, bool QLDS>
 __global__ __launch_bounds__(256) void finish_survivors_kernel(const float *__restrict__ E, int32_t D, const float *__restrict__ Q,
                                                                const double *__restrict__ norm_b, const int64_t *__restrict__ created,
