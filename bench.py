@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline + parity)")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
-    ap.add_argument("--cpu-sample-queries", type=int, default=32)
+    ap.add_argument("--cpu-sample-queries", type=int, default=96)
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of the headline shape, FETCH_SIZE and "
                          "WRITE_SIZE, before this process touches the GPU); the committed figure of the same shape is quoted instead")
