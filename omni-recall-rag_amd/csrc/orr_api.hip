@@ -2108,10 +2108,6 @@ int screen_i8_in_ranges(orr_index *idx, const BatchArgs &a, int64_t n, const orr
 // Records ([B][kprime+1]) land in pinned host memory (*recs_host) when host_records is set
 // and they are small, otherwise in idx->ws_cand (*recs_host = nullptr).  *q_host points at
 // the query vectors in host memory (valid until the next call).  Caller holds the lock.
-// up to this many queries the tail of the two-stage pass is one launch (finish_survivors: four lanes per survivor; 1M x 3072
-// rows, 128 / 256 queries: 1.016 -> 0.984 / 1.43 -> 1.39 ms per batch; 10M rows x 256: even; beyond, the survivors of a batch
-// are too many for four lanes each)
-
 int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host_records, const float **q_host,
                    const orr_candidate **recs_host)
 {
