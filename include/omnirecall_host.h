@@ -107,10 +107,14 @@ void          orrh_service_destroy(orrh_service *svc);
  * merged exactly like a multi-GPU search (orr_search_shard + orr_merge_candidates).  A deleted document
  * and a document whose chunk list was replaced (InMemoryIngestionStore.cs:17-25, 50-55) lose their rows in
  * place (orr_index_delete_rows: no reseal, row ids of the others unchanged); a replaced list then counts
- * as new.  Older timestamps, a different embedding dimension, more than 8 shards or more than a quarter of
- * a shard deleted trigger a full rebuild.  Counters for tests/metrics: */
+ * as new.  With eight shards in place the next upload MERGES the delta shards (all but the oldest) and the
+ * new chunks into one shard, the oldest -- the large one of a corpus that grows by uploads -- staying on the
+ * device untouched (while the deltas together are smaller than it).  Older timestamps, a different embedding
+ * dimension or more than a quarter of a shard deleted (after compaction) trigger a full rebuild.  Counters
+ * for tests/metrics: */
 void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebuilds, int64_t *delta_builds);
 int64_t orrh_service_tombstoned_rows(orrh_service *svc);    /* rows dropped in place so far */
+int64_t orrh_service_delta_merges(orrh_service *svc);       /* times the delta shards were merged into one (above) */
 int64_t orrh_service_compactions(orrh_service *svc);        /* shards compacted in place (orr_index_compact) instead of rebuilt, when more than a
                                                                quarter of a shard's rows had been dropped */
 /* SearchAsync(query, topK) with the query embedding supplied by the caller (the

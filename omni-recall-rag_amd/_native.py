@@ -170,6 +170,8 @@ host.orrh_service_tombstoned_rows.restype = _i64
 host.orrh_service_tombstoned_rows.argtypes = [_vp]
 host.orrh_service_compactions.restype = _i64
 host.orrh_service_compactions.argtypes = [_vp]
+host.orrh_service_delta_merges.restype = _i64
+host.orrh_service_delta_merges.argtypes = [_vp]
 host.orrh_service_destroy.restype = None
 host.orrh_service_destroy.argtypes = [_vp]
 host.orrh_service_search_json.restype = C.c_int
@@ -208,7 +210,7 @@ EXPORTED_HOST_SYMBOLS = ["orrh_is_blank", "orrh_lower_invariant", "orrh_query_te
                          "orrh_round4", "orrh_has_sufficient_evidence", "orrh_format_score_f4", "orrh_last_error", "orrh_store_create", "orrh_store_destroy",
                          "orrh_store_upsert_document", "orrh_store_upsert_chunks", "orrh_store_delete_document",
                          "orrh_store_chunk_count", "orrh_store_import_cosmos_json", "orrh_store_export_cosmos_json", "orrh_service_create", "orrh_service_destroy",
-                         "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_service_compactions", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
+                         "orrh_service_search_json", "orrh_service_stats", "orrh_service_tombstoned_rows", "orrh_service_compactions", "orrh_service_delta_merges", "orrh_free", "orrh_batcher_create", "orrh_batcher_destroy",
                          "orrh_batcher_search", "orrh_batcher_search_at", "orrh_batcher_stats"]
 
 

@@ -105,7 +105,7 @@ struct orrh_service {
     int32_t dim = 0;
     uint64_t built_version = ~0ull;
     int64_t next_id = 0;
-    int64_t full_rebuilds = 0, delta_builds = 0, tombstoned_rows = 0, compactions = 0;
+    int64_t full_rebuilds = 0, delta_builds = 0, tombstoned_rows = 0, compactions = 0, delta_merges = 0;
 };
 
 namespace {
@@ -264,13 +264,51 @@ int ensure_index(orrh_service *svc)
             for (const auto &c : it->second) added.push_back(c);
             added_stamps[doc] = st->chunk_stamp[doc];
         }
-    bool delta_ok = !changed && !svc->shards.empty() && svc->shards.size() < 8 && !added.empty();
+    bool delta_ok = !changed && !svc->shards.empty() && !added.empty();
     if (delta_ok) {
         int64_t newest = svc->shards[0].max_created;
         for (const auto &sh : svc->shards) newest = std::max(newest, sh.max_created);
         const int32_t d = majority_dim(added);
         for (const auto &c : added) delta_ok = delta_ok && c.created_ticks > newest;      // strictly newer: ties keep enumeration order
         delta_ok = delta_ok && (d == svc->dim || d == 0);
+    }
+    if (delta_ok && svc->shards.size() >= 8) {
+        // Eight shards already: the DELTA shards (all but the oldest) and the new chunks become ONE shard; the oldest -- the
+        // large one of a corpus that grows by uploads -- stays on the device untouched.  The delta shards are strictly newer
+        // than one another in the order they were added, so their live chunks concatenated newest shard first (each in its own
+        // enumeration order) are what a rebuild would enumerate for those documents.  Only worth it while the deltas together
+        // are smaller than that oldest shard; otherwise everything is rebuilt below.
+        size_t delta_rows = added.size();
+        for (size_t i = 0; i + 1 < svc->shards.size(); ++i) delta_rows += svc->shards[i].chunks.size() - (size_t)svc->shards[i].n_dead;
+        const Shard &base = svc->shards.back();
+        if (delta_rows < base.chunks.size() - (size_t)base.n_dead) {
+            std::vector<Chunk> merged = std::move(added);
+            std::map<std::string, uint64_t> stamps = added_stamps;
+            for (size_t i = 0; i + 1 < svc->shards.size(); ++i) {
+                Shard &sh = svc->shards[i];
+                for (size_t p = 0; p < sh.chunks.size(); ++p)
+                    if (sh.dead.empty() || !sh.dead[p]) merged.push_back(std::move(sh.chunks[p]));
+                for (const auto &kv : sh.doc_stamps) stamps[kv.first] = kv.second;
+            }
+            Shard one;
+            int r = build_shard(svc, std::move(merged), svc->dim, &one);
+            if (r != ORR_OK) {                              // (the mirror's chunks were moved out: nothing to fall back on but a rebuild)
+                free_shards(svc);
+                svc->built_version = ~0ull;
+                return r;
+            }
+            one.doc_stamps = stamps;
+            Shard keep = std::move(svc->shards.back());
+            svc->shards.pop_back();
+            free_shards(svc);
+            svc->shards.push_back(std::move(one));
+            svc->shards.push_back(std::move(keep));
+            svc->delta_merges++;
+            assign_row_bases(svc);
+            svc->built_version = st->chunks_version;
+            return ORR_OK;
+        }
+        delta_ok = false;
     }
     if (delta_ok) {
         Shard sh;
@@ -429,6 +467,13 @@ void orrh_service_stats(orrh_service *svc, int32_t *n_shards, int64_t *full_rebu
     if (n_shards) *n_shards = (int32_t)svc->shards.size();
     if (full_rebuilds) *full_rebuilds = svc->full_rebuilds;
     if (delta_builds) *delta_builds = svc->delta_builds;
+}
+
+int64_t orrh_service_delta_merges(orrh_service *svc)
+{
+    if (!svc) return 0;
+    std::lock_guard<std::mutex> lock(svc->mu);
+    return svc->delta_merges;
 }
 
 int64_t orrh_service_compactions(orrh_service *svc)

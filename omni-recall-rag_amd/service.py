@@ -130,7 +130,8 @@ class RecallSearchService:
                                   C.cast(C.byref(delta), C.c_void_p))
         return {"shards": n.value, "full_rebuilds": full.value, "delta_builds": delta.value,
                 "tombstoned_rows": int(N.host.orrh_service_tombstoned_rows(self._h)),
-                "compactions": int(N.host.orrh_service_compactions(self._h))}
+                "compactions": int(N.host.orrh_service_compactions(self._h)),
+                "delta_merges": int(N.host.orrh_service_delta_merges(self._h))}
 
     def close(self):
         if self._h:

@@ -233,7 +233,7 @@ def test_uploads_after_the_first_build_become_delta_shards():
     for sut_limit in (300, 10**6):
         sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=sut_limit, now_ticks=NOW)
         check(sut)
-        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0, "tombstoned_rows": 0, "compactions": 0}
+        assert sut.Stats() == {"shards": 1, "full_rebuilds": 1, "delta_builds": 0, "tombstoned_rows": 0, "compactions": 0, "delta_merges": 0}
         t = base_time + 10**9 * (1 if sut_limit == 300 else 5)
         for step in range(3):                                  # three rounds of newer uploads -> three delta shards
             for j in range(2):
@@ -270,6 +270,68 @@ def test_uploads_after_the_first_build_become_delta_shards():
         upload("old-03", base_time + 3 * 1000 + 1)
         for g in gone:
             upload(g, base_time + int(g[4:]) * 1000 + 1)
+    store.close()
+
+
+@pytest.mark.gpu
+def test_the_ninth_shard_merges_the_delta_shards_and_leaves_the_oldest_alone():
+    """A corpus that grows by uploads: with eight shards in place the next upload merges the seven delta shards and the new
+    chunks into ONE shard in front of the oldest (the large one), which stays on the device as it is -- no full rebuild.
+    Rows a delta shard lost in place before the merge stay out; results equal the oracle over the store after every step."""
+    S = _svc()
+    rng = np.random.default_rng(77)
+    store = S.InMemoryIngestionStore()
+    words = ["alpha", "beta", "gamma", "delta", "kubernetes", "azure"]
+    chunks_flat = []
+
+    def upload(doc, created, n_chunks=5):
+        store.UpsertDocument(S.CosmosDocumentRecord(doc, doc + ".md", created))
+        cs = [S.CosmosChunkRecord("%s:%04d" % (doc, i), doc, i, " ".join(rng.choice(words, 8)),
+                                  rng.standard_normal(16).astype(np.float32), created) for i in range(n_chunks)]
+        store.UpsertChunks(cs)
+        chunks_flat.extend(cs)
+
+    qv = rng.standard_normal(16).astype(np.float32)
+    base_time = NOW - 60 * 864000000000
+    for d in range(40):
+        upload("base-%02d" % d, base_time + d * 1000)
+    sut = S.RecallSearchService(store, S.StubQueryEmbeddingClient(qv), candidate_limit=10**6, now_ticks=NOW)
+
+    def check(note):
+        cor = orc.OracleCorpus([c.Embedding for c in chunks_flat], [c.CreatedAtTicks for c in chunks_flat], [c.Content for c in chunks_flat])
+        for text in ("alpha kubernetes", "the gamma", "zzz"):
+            body = sut.Search(text, 12)
+            rows, _, rounded = cor.search(qv, text, NOW, 12, candidate_limit=10**6)
+            assert [(c["chunkId"], c["score"]) for c in body["citations"]] == [(chunks_flat[r].Id, rd) for r, rd in zip(rows, rounded)], note
+
+    check("built")
+    t = base_time + 10**9
+    for step in range(7):                                      # seven rounds of newer uploads: seven delta shards
+        t += 5000
+        upload("up-%d-a" % step, t, 6)
+        upload("up-%d-b" % step, t + 1, 1)
+        check("delta %d" % step)
+    st = sut.Stats()
+    assert st["shards"] == 8 and st["delta_builds"] == 7 and st["full_rebuilds"] == 1 and st["delta_merges"] == 0, st
+    store.DeleteDocument("up-2-b")                             # a row dropped in place inside a delta shard (a seventh of it)
+    chunks_flat[:] = [c for c in chunks_flat if c.DocumentId != "up-2-b"]
+    check("deleted inside a delta shard")
+    t += 5000
+    upload("up-7", t, 6)                                       # the ninth shard: merge
+    check("merged")
+    st = sut.Stats()
+    assert st["shards"] == 2 and st["delta_merges"] == 1 and st["full_rebuilds"] == 1 and st["tombstoned_rows"] == 1, st
+    for step in range(8, 11):                                  # and on it goes: new delta shards in front of the merged one
+        t += 5000
+        upload("up-%d" % step, t, 2)
+        check("delta after the merge %d" % step)
+    st = sut.Stats()
+    assert st["shards"] == 5 and st["full_rebuilds"] == 1, st
+    store.DeleteDocument("up-3-b")                             # a document that now lives in the merged shard
+    chunks_flat[:] = [c for c in chunks_flat if c.DocumentId != "up-3-b"]
+    check("deleted inside the merged shard")
+    assert sut.Stats()["full_rebuilds"] == 1
+    sut.close()
     store.close()
 
 
