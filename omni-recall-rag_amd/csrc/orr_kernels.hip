@@ -423,11 +423,43 @@ __global__ __launch_bounds__(256) void kw_alias_kernel(const uint32_t *__restric
     term_word_off[t] = bm >= 0 ? bm_store_delta + (int64_t)bm * words_per_term : (int64_t)t * words_per_term;
 }
 
+// Both steps in ONE workgroup for the few terms of a small batch (a one-query call pays every launch boundary of the keyword
+// chain in front of its stream): the counts live in LDS.
+constexpr int kKwAliasSmall = 512;
+__global__ __launch_bounds__(256) void kw_alias_small_kernel(const KwHit *__restrict__ hits, const unsigned long long *__restrict__ counter,
+                                                             uint32_t max_hits, const int32_t *__restrict__ tok_bm_index, int32_t n_terms,
+                                                             int64_t bm_store_delta, int64_t words_per_term,
+                                                             int64_t *__restrict__ term_word_off, uint8_t *__restrict__ alias)
+{
+    __shared__ uint32_t cnt[kKwAliasSmall], tok[kKwAliasSmall];
+    for (int t = threadIdx.x; t < n_terms; t += blockDim.x) { cnt[t] = 0u; tok[t] = 0u; }
+    __syncthreads();
+    uint32_t n_hits = (uint32_t)(*counter >> 32);
+    if (n_hits > max_hits) n_hits = max_hits;
+    for (uint32_t i = threadIdx.x; i < n_hits; i += blockDim.x) {
+        const KwHit h = hits[i];
+        atomicAdd(&cnt[h.term], 1u);
+        tok[h.term] = h.token;                         // (the only writer where the count ends up 1)
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_terms; t += blockDim.x) {
+        int32_t bm = -1;
+        if (cnt[t] == 1u && tok_bm_index) bm = tok_bm_index[tok[t]];
+        alias[t] = bm >= 0 ? 1 : 0;
+        term_word_off[t] = bm >= 0 ? bm_store_delta + (int64_t)bm * words_per_term : (int64_t)t * words_per_term;
+    }
+}
+
 hipError_t launch_kw_alias(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits, int32_t n_terms,
                            const int32_t *tok_bm_index, int64_t bm_store_delta, int64_t words_per_term, uint32_t *term_cnt,
                            uint32_t *term_tok, int64_t *term_word_off, uint8_t *alias, hipStream_t s)
 {
     if (n_terms <= 0) return hipSuccess;
+    if (n_terms <= 64) {                               // (a handful of queries: beyond, many workgroups count the hits faster)
+        hipLaunchKernelGGL(kw_alias_small_kernel, dim3(1), dim3(256), 0, s, hits, counter, max_hits, tok_bm_index, n_terms, bm_store_delta,
+                           words_per_term, term_word_off, alias);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kw_term_hits_kernel, dim3(64), dim3(256), 0, s, hits, counter, max_hits, term_cnt, term_tok);
     hipLaunchKernelGGL(kw_alias_kernel, dim3((unsigned)((n_terms + 255) / 256)), dim3(256), 0, s, term_cnt, term_tok, tok_bm_index, n_terms,
                        bm_store_delta, words_per_term, term_word_off, alias);
@@ -814,11 +846,38 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
     return hipGetLastError();
 }
 
+// The floor from MANY lists (a one-query call's sampled stream leaves 128 of them): the k-th best of the lists' HEADS belongs to
+// k distinct rows, so it is a valid floor, and it is the k-th best row's key unless two of the k best rows share a list
+// (k^2 / (2 lists) of the time: the floor is then the (k+1)-th best).  One wave per query instead of sixteen merging every list.
+__global__ __launch_bounds__(64) void select_floor_heads_kernel(const SelEntry *__restrict__ sel, int32_t n_seg, int32_t seg_stride,
+                                                                int32_t kprime, unsigned long long *__restrict__ tau_out, FloorOut floor)
+{
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const SelEntry *mine = sel + (int64_t)b * seg_stride * kSelWidth;
+    unsigned long long k = 0ull;
+    uint32_t p = 0xFFFFFFFFu;
+    for (int sg = lane; sg < n_seg; sg += 64) {
+        const SelEntry e = mine[(int64_t)sg * kSelWidth];
+        if (better(e.key, e.pos, k, p)) { k = e.key; p = e.pos; }
+    }
+    wave_sort(k, p, lane);
+    const unsigned long long kth = __shfl(k, kprime - 1, 64);
+    if (lane == 0) {
+        tau_out[b] = kth;
+        if (floor.floor_key) two_stage_floor_of(kth, floor.eps3, floor.eps1, floor.floor_key + b, floor.L + b);
+    }
+}
+
 hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
                                       int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor)
 {
     if (B <= 0 || sample_seg <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
+    static const bool full = getenv("ORR_FLOOR_FULL") != nullptr;      // (A/B)
+    if (floor.floor_key && sample_seg >= 8 * kprime && !full) {        // (a two-stage pass's floor: any k distinct rows' k-th key serves)
+        hipLaunchKernelGGL(select_floor_heads_kernel, dim3((unsigned)B), dim3(64), 0, s, sel, sample_seg, n_seg_total, kprime, tau_out, floor);
+        return hipGetLastError();
+    }
     const KwView nokw{nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)B), dim3(1024), 0, s, sel, sample_seg, n_seg_total, kprime,
                        (int64_t)0, (int64_t)0, nullptr, nullptr, (int64_t)0, nullptr, nullptr, nullptr, nokw, 0, 0.0,
