@@ -2071,7 +2071,7 @@ int two_stage_tail(orr_index *idx, const BatchArgs &a, int32_t kprime, int64_t n
 // ranges' count words are formed on the keyword stream while the earlier ranges are multiplied (released when the main
 // stream gets here), every launch draws its output tiles from its own set of tickets.
 int screen_i8_in_ranges(orr_index *idx, const BatchArgs &a, int64_t n, const orr::KwView &kw, orr::FusedEpilogue epi, int n_ranges,
-                        const int64_t *range_row, double plane_bytes_per_row, hipStream_t s)
+                        const int64_t *range_row, double plane_bytes_per_row, hipStream_t s, bool tickets_cleared)
 {
     const int32_t B = a.B;
     // algorithmic bytes: the int8 rows once, per row its constants (rowc 16 B, i8_rowf 16 B) and, with query terms,
@@ -2092,7 +2092,7 @@ int screen_i8_in_ranges(orr_index *idx, const BatchArgs &a, int64_t n, const orr
     }
     // output-tile tickets of the 16 x 16 x 64 form: eight counters per launch, cleared once per pass
     ORR_TRY(idx->ws_tickets.reserve(sizeof(uint32_t) * 8 * 16));
-    HIP_TRY(hipMemsetAsync(idx->ws_tickets.p, 0, sizeof(uint32_t) * 8 * 16, s));
+    if (!tickets_cleared) HIP_TRY(hipMemsetAsync(idx->ws_tickets.p, 0, sizeof(uint32_t) * 8 * 16, s));
     for (int r = 0; r < n_ranges; ++r) {
         if (r > 0) HIP_TRY(hipStreamWaitEvent(s, idx->ev_range[r - 1], 0));
         epi.tickets = idx->ws_tickets.as<uint32_t>() + 8 * r;
@@ -2371,8 +2371,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
     if (dev_norms) {
         HIP_TRY(hipStreamWaitEvent(s, idx->ev_q, 0));
-        HIP_TRY(orr::launch_patch_query_norms(idx->ws_qc.as<orr::QueryConst>(), idx->ws_norm_a.as<double>(), B, batched_score, s));
-        HIP_TRY(hipMemcpyAsync(idx->pin_norm.p, idx->ws_norm_a.p, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(orr::launch_patch_query_norms(idx->ws_qc.as<orr::QueryConst>(), idx->ws_norm_a.as<double>(), B, batched_score, s,
+                                              idx->pin_norm.as<double>()));
     }
     // per-row selection constants do not depend on the keyword side: enqueued before the main stream waits for it
     const double2 *d_rowc_early = nullptr;
@@ -2459,7 +2459,11 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             epi.qf = idx->ws_fqf.as<float4>();
             epi.rowc = d_rowc; epi.qc = idx->ws_qc.as<orr::QueryConst>(); epi.kw = kw;
             epi.cnt = idx->ws_fcnt.as<uint32_t>(); epi.buf = idx->ws_fbuf.as<orr::SelEntry>(); epi.cap = kCap;
-            if (!counters_cleared) HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * 3 * (size_t)B, s));
+            // (the counters are cleared by the query-constants launch in front of the screening launches; the streaming forms
+            // cleared them with the queries' images)
+            const bool clear_with_consts = !counters_cleared && !ts_gemv;
+            if (!counters_cleared && !clear_with_consts) HIP_TRY(hipMemsetAsync(idx->ws_fcnt.p, 0, sizeof(uint32_t) * 3 * (size_t)B, s));
+            ORR_TRY(idx->ws_tickets.reserve(sizeof(uint32_t) * 8 * 16));
             if (two_stage) {
                 // ---- two-stage: floor from the k-th best split-pass score of the prefix; ONE plain-bf16
                 // product over ALL rows keeps every row that can still reach it; those are re-scored
@@ -2519,7 +2523,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 }
                 // the screening GEMM runs on the int8 shadow where there is one (K2j), else on the bf16 shadow (K2c),
                 // else it converts the fp32 rows itself
-                bool gemm_i8 = false;
+                bool gemm_i8 = false, tickets_cleared = false;
                 if (idx->opt_two_stage == 1 && !ts_gemv) {
                     ORR_TRY(ensure_i8_shadow(idx));
                     gemm_i8 = idx->i8_ready;
@@ -2541,7 +2545,10 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), idx->ws_tskey.as<unsigned long long>(), B,
                                                            idx->ws_fqf.as<float4>(), s, gemm_i8 ? idx->ws_q8s1.as<float>() : nullptr,
                                                            gemm_i8 ? idx->ws_q8err.as<double>() + B : nullptr,
-                                                           gemm_i8 ? idx->ws_fqf.as<float4>() + B : nullptr));
+                                                           gemm_i8 ? idx->ws_fqf.as<float4>() + B : nullptr,
+                                                           clear_with_consts ? idx->ws_fcnt.as<uint32_t>() : nullptr, 3 * B,
+                                                           idx->ws_tickets.as<uint32_t>(), 8 * 16));
+                    tickets_cleared = true;
                     epi.qf16 = gemm_i8 ? idx->ws_fqf.as<float4>() + B : nullptr;
                 }
                 epi.tau = idx->ws_tskey.as<unsigned long long>();
@@ -2555,7 +2562,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                         ORR_TRY(idx->ws_qtiled.reserve(orr::i8_tiled_bytes(B, idx->dim)));
                         HIP_TRY(orr::launch_i8_tile_queries(idx->ws_q8.p, B, idx->dim, idx->ws_qtiled.p, s));
                     }
-                    ORR_TRY(screen_i8_in_ranges(idx, a, n, kw, epi, n_ranges, range_row, plane_bytes_per_row, s));
+                    ORR_TRY(screen_i8_in_ranges(idx, a, n, kw, epi, n_ranges, range_row, plane_bytes_per_row, s, tickets_cleared));
                 } else if (ts_i8) {
                     Timed t(idx, "screen_gemv_i8", 1.0 * (double)n * idx->dim + 28.0 * (double)n + 2.0 * (double)B * idx->dim);   // per row: scale, two relative norms (12 B), normB and created (16 B)
                     HIP_TRY(orr::launch_screen_gemv_i8(idx->ws_q8.p, idx->ws_q8s1.as<float>(), idx->ws_q8err.as<double>(), B, idx->emb_i8.p,
@@ -2582,7 +2589,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                 Timed t(idx, "select_floor", 0.0);
                 HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kprime, d_tau, s));
             }
-            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float4>(), s));
+            HIP_TRY(orr::launch_fused_query_consts(idx->ws_qc.as<orr::QueryConst>(), d_tau, B, idx->ws_fqf.as<float4>(), s, nullptr, nullptr, nullptr,
+                                                   clear_with_consts ? idx->ws_fcnt.as<uint32_t>() : nullptr, 3 * B));
             epi.tau = d_tau;
             {
                 Timed t(idx, "gemm_dot_bf16x3_fused", 4.0 * (double)(n - dotf_rows) * idx->dim + 4.0 * (double)B * idx->dim);

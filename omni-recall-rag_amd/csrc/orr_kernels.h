@@ -157,7 +157,8 @@ struct QueryConst {
 };
 
 // qc[b].norm_a / inv_sqrt_na / use_cos from norms computed on the device (launch_dot_exact, self_norm over the queries).
-hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s);
+hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s,
+                                    double *norm_host = nullptr);        // norm_host (optional, pinned): the norms for the host as well
 
 // Per-row selection constants for a batch: out[r] = {1/sqrt(normB) or 0, recency * 0.1}.
 hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64_t now_ticks, int64_t n_rows,
@@ -233,8 +234,10 @@ bool screen_i8_uses_tile16(int32_t B, int64_t n_rows, int32_t D, int64_t plane_s
 // qf16 (optional, [B]): the same constants made safe for a NaN-dropping test (fused_epilogue16) -- finite qx / qz, a query with
 // anything non-finite turned into "every pair passes" (qx = qz = 0, floor -inf) -- with .w = the largest finite query bound
 // term of the batch in EVERY entry.
+// zero_a / zero_b (optional): words this launch clears as well (the pass's counters, the screening launches' tickets).
 hipError_t launch_fused_query_consts(const QueryConst *qc, const unsigned long long *tau, int32_t B, float4 *qf, hipStream_t s,
-                                     const float *i8_qs1 = nullptr, const double *i8_qerr2 = nullptr, float4 *qf16 = nullptr);
+                                     const float *i8_qs1 = nullptr, const double *i8_qerr2 = nullptr, float4 *qf16 = nullptr,
+                                     uint32_t *zero_a = nullptr, int32_t n_a = 0, uint32_t *zero_b = nullptr, int32_t n_b = 0);
 // K2c (orr_screen.hip): plain-bf16 screening GEMM (256 x 256 x 64 tiles, LDS-DMA staging) over TILED bf16
 // images of the embeddings (the shard's shadow) and of the batch's queries; S or the fused epilogue as above.
 size_t bf16_tiled_bytes(int64_t n_rows, int32_t D);
