@@ -2240,6 +2240,15 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
     const uint32_t kw_max_hits = kws.max_hits;
 
     g_ht.mark(1);
+    // the hi/lo bf16 split of the queries, launched in front of the first kernel that reads it (the int8 forms never do)
+    bool queries_split = false;
+    auto need_split = [&]() -> int {
+        if (queries_split) return ORR_OK;
+        queries_split = true;
+        ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
+        HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+        return ORR_OK;
+    };
     // ---- cosine numerators
     double *d_dot = nullptr;
     float *d_dotf = nullptr;
@@ -2273,8 +2282,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             if (ts_i8) {
                 // (quantised above, before the keyword side was prepared)
             } else {
-                ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
-                HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
+                ORR_TRY(need_split());
             }
         } else if (B < ts_min_batch || (B <= 64 && !ts_eligible)) {   // HBM-bound streaming form over all rows, 32 queries per launch
             for (int32_t b0 = 0; b0 < B; b0 += 32) {
@@ -2286,8 +2294,6 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             {   // split bf16: queries split once; with enough rows the GEMM over everything behind a
                 // sampled prefix runs with the fused scoring epilogue (launched further down, once the
                 // floor keys exist) and only the prefix's dots go through HBM
-                ORR_TRY(idx->ws_qsplit.reserve(sizeof(float) * (size_t)B * idx->dim));
-                HIP_TRY(orr::launch_split_queries(d_q, B, idx->dim, idx->ws_qsplit.p, s));
                 const int32_t n_seg_all = (int32_t)((n + orr::kSelSegRows - 1) / orr::kSelSegRows);
                 two_stage = idx->opt_two_stage != 0 && !a.no_fuse && n_seg_all >= 48 && std::max<int32_t>(1, a.topk) <= orr::kSelWidth;
                 fused_sample_seg = ((idx->opt_fuse_epilogue || two_stage) && !a.no_fuse && n_seg_all >= 48)
@@ -2314,6 +2320,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     Timed t(idx, "screen_i8_prefix", 1.0 * (double)pre_rows * idx->dim + 1.0 * (double)B * idx->dim + 4.0 * (double)B * (double)pre_rows);
                     HIP_TRY(orr::launch_screen_i8_dots(idx->ws_qtiled.p, B, idx->emb_i8.p, pre_rows, idx->dim, d_dotf, dotf_rows, s));
                 } else {
+                    ORR_TRY(need_split());
                     Timed t(idx, "gemm_dot_bf16x3", 4.0 * (double)dotf_rows * idx->dim + 4.0 * (double)B * idx->dim + 4.0 * (double)B * (double)dotf_rows);
                     HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, dotf_rows, idx->dim, d_dotf, dotf_rows, nullptr, 3, s));
                     bf16_split = true;
@@ -2500,6 +2507,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     const bool pre_lists = ts_i8 && orr::screen_gemv_i8_prefix_makes_lists(idx->dim);   // sorted lists straight from the kernel
                     ORR_TRY(idx->ws_psel.reserve(sizeof(orr::SelEntry) * (size_t)B * cap_p));
                     if (pre_lists) pre.buf = idx->ws_psel.as<orr::SelEntry>();
+                    if (!ts_i8) ORR_TRY(need_split());
                     {
                         Timed t(idx, "screen_gemv_prefix", (ts_i8 ? 1.0 : 2.0) * (double)dotf_rows * idx->dim + 2.0 * (double)B * idx->dim);
                         if (ts_i8)
@@ -2569,6 +2577,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                        idx->i8_scale.as<float>(), idx->i8_rel_err.as<float>(), idx->i8_rel_hat.as<float>(),
                                                        idx->d_norm_b, idx->d_created, a.now_ticks, n, idx->dim, epi, false, s));
                 } else if (ts_gemv) {
+                    ORR_TRY(need_split());
                     Timed t(idx, "screen_gemv_bf16", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_gemv_bf16(idx->ws_qsplit.p, B, idx->emb_shadow.p, n, idx->dim, epi, s));
                 } else if (idx->opt_two_stage == 1 && idx->shadow_ready) {
@@ -2577,6 +2586,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     Timed t(idx, "screen_bf16_fused", 2.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_screen_bf16(idx->ws_qtiled.p, B, idx->emb_shadow.p, 0, n, idx->dim, nullptr, 0, &epi, s));
                 } else {
+                    ORR_TRY(need_split());
                     Timed t(idx, "gemm_dot_bf16x1_fused", 4.0 * (double)n * idx->dim + 2.0 * (double)B * idx->dim);
                     HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, 0, n, idx->dim, nullptr, 0, &epi, 1, s));
                 }
@@ -2593,6 +2603,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                    clear_with_consts ? idx->ws_fcnt.as<uint32_t>() : nullptr, 3 * B));
             epi.tau = d_tau;
             {
+                ORR_TRY(need_split());
                 Timed t(idx, "gemm_dot_bf16x3_fused", 4.0 * (double)(n - dotf_rows) * idx->dim + 4.0 * (double)B * idx->dim);
                 HIP_TRY(orr::launch_gemm_dot_bf16x3(idx->ws_qsplit.p, B, idx->d_emb, dotf_rows, n, idx->dim, nullptr, 0, &epi, 3, s));
             }
