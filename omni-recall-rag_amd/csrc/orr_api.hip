@@ -2375,11 +2375,12 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             else qc[b].inv_sqrt_na = 1.0 / std::sqrt(qc[b].norm_a);        // NaN stays NaN
         }
     }
-    HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
-    if (dev_norms) {
+    if (dev_norms) {        // (the kernel that adds the norms reads the host's constants in place: no upload command)
         HIP_TRY(hipStreamWaitEvent(s, idx->ev_q, 0));
         HIP_TRY(orr::launch_patch_query_norms(idx->ws_qc.as<orr::QueryConst>(), idx->ws_norm_a.as<double>(), B, batched_score, s,
-                                              idx->pin_norm.as<double>()));
+                                              idx->pin_norm.as<double>(), qc));
+    } else {
+        HIP_TRY(hipMemcpyAsync(idx->ws_qc.p, qc, sizeof(orr::QueryConst) * (size_t)B, hipMemcpyHostToDevice, s));
     }
     // per-row selection constants do not depend on the keyword side: enqueued before the main stream waits for it
     const double2 *d_rowc_early = nullptr;

@@ -158,7 +158,8 @@ struct QueryConst {
 
 // qc[b].norm_a / inv_sqrt_na / use_cos from norms computed on the device (launch_dot_exact, self_norm over the queries).
 hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s,
-                                    double *norm_host = nullptr);        // norm_host (optional, pinned): the norms for the host as well
+                                    double *norm_host = nullptr,         // norm_host (optional, pinned): the norms for the host as well
+                                    const QueryConst *qc_host = nullptr);   // qc_host (optional, pinned): the constants come from there, not from qc
 
 // Per-row selection constants for a batch: out[r] = {1/sqrt(normB) or 0, recency * 0.1}.
 hipError_t launch_row_consts(const double *norm_b, const int64_t *created, int64_t now_ticks, int64_t n_rows,

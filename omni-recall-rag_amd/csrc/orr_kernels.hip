@@ -32,23 +32,26 @@ __global__ __launch_bounds__(256) void row_consts_kernel(const double *__restric
 // Query norms computed on the device (queries that already live there): fills the norm-dependent fields of the
 // per-query constants exactly as the host does for host-resident queries.
 __global__ void patch_query_norms_kernel(QueryConst *__restrict__ qc, const double *__restrict__ norm_a, int32_t B, int32_t batched,
-                                         double *__restrict__ norm_host)
+                                         double *__restrict__ norm_host, const QueryConst *__restrict__ qc_host)
 {
     const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double na = norm_a[b];
-    qc[b].norm_a = na;
+    QueryConst c = qc_host ? qc_host[b] : qc[b];          // (qc_host: the host's copy in pinned memory, read in place -- no upload command)
+    c.norm_a = na;
     if (norm_host) norm_host[b] = na;                     // (pinned host memory: no copy command behind this launch)
-    if (batched && qc[b].use_cos) {
-        if (na <= 0.0) qc[b].use_cos = 0;                 // guard :84 -> cosine 0 for every row
-        else qc[b].inv_sqrt_na = 1.0 / sqrt(na);          // NaN stays NaN
+    if (batched && c.use_cos) {
+        if (na <= 0.0) c.use_cos = 0;                     // guard :84 -> cosine 0 for every row
+        else c.inv_sqrt_na = 1.0 / sqrt(na);              // NaN stays NaN
     }
+    qc[b] = c;
 }
 
-hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s, double *norm_host)
+hipError_t launch_patch_query_norms(QueryConst *qc, const double *norm_a, int32_t B, bool batched, hipStream_t s, double *norm_host,
+                                    const QueryConst *qc_host)
 {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(patch_query_norms_kernel, dim3((B + 255) / 256), dim3(256), 0, s, qc, norm_a, B, batched ? 1 : 0, norm_host);
+    hipLaunchKernelGGL(patch_query_norms_kernel, dim3((B + 255) / 256), dim3(256), 0, s, qc, norm_a, B, batched ? 1 : 0, norm_host, qc_host);
     return hipGetLastError();
 }
 
