@@ -81,6 +81,9 @@ def parse_args(argv=None):
                          "(orr_cluster_set_option exchange=1)")
     ap.add_argument("--cluster-oversubscribe", action="store_true",
                     help="rehearsal only: --mode cluster with more shards than visible devices (shards share cards, device g %% visible)")
+    ap.add_argument("--dist-rehearsal", action="store_true",
+                    help="rehearsal only: take the multi-rank branch (torch.distributed, the sharded front end, its legs) with the ranks "
+                         "there are -- with --gpus 1 under torch.distributed.run that is RCCL itself with one rank on a one-GPU box")
     ap.add_argument("--strong-rows", type=int, default=10_000_000, help="total rows of the fixed-N (strong-scaling) leg of a multi-GPU run; 0 = skip")
     ap.add_argument("--cluster-leg-rows", type=int, default=1_000_000, help="rows per device of the in-process orr_cluster leg of a multi-GPU run; 0 = skip")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
@@ -709,7 +712,7 @@ def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     launched = "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and args.mode == "ranks" and not launched:
+    if (args.gpus > 1 or args.dist_rehearsal) and args.mode == "ranks" and not launched:
         spawn_ranks(args, argv)                    # never returns
     cluster_mode = args.mode == "cluster"          # (one device too: a one-shard cluster, e.g. to rehearse the RCCL exchange on a one-GPU box)
     world = 1 if cluster_mode else int(os.environ.get("WORLD_SIZE", "1"))
@@ -717,7 +720,7 @@ def main():
     if not cluster_mode and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     probe = host_probe() if rank == 0 else {}      # child processes only; before the first GPU call of this process
-    if rank == 0 and world == 1 and not cluster_mode and not args.no_pmc:
+    if rank == 0 and world == 1 and not cluster_mode and not args.no_pmc and not args.dist_rehearsal:
         try:
             probe["pmc"] = measure_traffic(args)       # (children too: the profiler must not meet a process that already holds the GPU)
         except Exception as exc:
@@ -765,7 +768,7 @@ def run(args, probe, state, cluster_mode, world, rank):
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_visible)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or args.dist_rehearsal:
         # (a collective that cannot complete -- a rank died -- raises after five minutes instead of the default ten, and the
         # survivors report it in the JSON line)
         if args.backend == "nccl":
@@ -806,7 +809,7 @@ def run(args, probe, state, cluster_mode, world, rank):
         head["kernels"] = {}
         head["query_tokenisation_ms_per_step"] = None
         front, idx = None, None
-    elif world == 1:
+    elif world == 1 and not args.dist_rehearsal:
         rows = args.rows_per_gpu or 10_000_000
         B = args.batch or 256
         # ---- leg: C2 (configs[1]) on its own 1M-row shard
@@ -858,6 +861,7 @@ def run(args, probe, state, cluster_mode, world, rank):
         idx = build_shard(P, syn, torch, rank, rows, dim, n_total, dev, args.set_option)
         setup_s["headline_corpus"] = time.perf_counter() - t0
         front = sharded.ShardedRecallSearch(idx, dim, coll_dev)
+        front.always_collect = bool(args.dist_rehearsal)
         ranks_seen = front.rccl_ranks_seen()
         head_leg = Leg("headline", workload_label(rows, dim, B, k, not args.no_terms, world), rows, n_total, B, terms=not args.no_terms)
         head = run_leg(head_leg, args, env, idx, front, syn)
@@ -900,6 +904,7 @@ def run(args, probe, state, cluster_mode, world, rank):
             idx_s = build_shard(P, syn, torch, rank, rows_s, dim, rows_s * world, dev, args.set_option)
             setup_s["strong_corpus"] = time.perf_counter() - t0
             front_s = sharded.ShardedRecallSearch(idx_s, dim, coll_dev)
+            front_s.always_collect = bool(args.dist_rehearsal)
             leg = Leg("strong", "fixed corpus (strong scaling): " + workload_label(rows_s, dim, 256, k, True, world), rows_s, rows_s * world, 256)
             r = run_leg(leg, args, env, idx_s, front_s, syn)
             r["scaling"] = "strong"
@@ -910,7 +915,7 @@ def run(args, probe, state, cluster_mode, world, rank):
             torch.cuda.empty_cache()
 
     cpu = parity = None
-    if rank == 0 and world == 1 and not cluster_mode and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not cluster_mode and not args.no_cpu_baseline and not args.dist_rehearsal:
         t0 = time.perf_counter()
         cpu, parity = oracle_leg(args, env, idx, syn, n_total, B, probe)
         setup_s["oracle_leg"] = time.perf_counter() - t0
@@ -920,7 +925,7 @@ def run(args, probe, state, cluster_mode, world, rank):
                        cluster_mode=cluster_mode)
         state["out"] = out
         emit(out)
-    if world > 1:
+    if world > 1 or args.dist_rehearsal:
         dist.barrier()
         dist.destroy_process_group()
     if idx is not None:

@@ -86,6 +86,7 @@ class ShardedRecallSearch:
         self.escalations = 0                   # passes repeated with the exact pass or a larger k' (for the uncertified queries only)
         self.escalated_queries = 0             # queries that went through such a repeat (summed over repeats)
         self._shard_search_done = None         # test hook: called with (records tensor, queries, k') between the shard search and the all-gather
+        self.always_collect = False            # rehearsals: issue the collectives with ONE rank too (RCCL itself on a one-GPU box)
 
     def _index_shard_search(self, q, terms, now, kprime, limit, out=None, mode=0, topk=0):
         # mode 0: the library picks the pass; 2: the exact pass (escalation after a failed certificate).
@@ -109,7 +110,7 @@ class ShardedRecallSearch:
 
     def rccl_ranks_seen(self) -> int:
         """Ranks that answer one all-gather on this group's backend (bench evidence that the RCCL path ran)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_collect:
             return 1
         mine = torch.tensor([self.rank], dtype=torch.int64, device=self.device)
         allr = torch.empty(self.world, dtype=torch.int64, device=self.device)
@@ -136,7 +137,7 @@ class ShardedRecallSearch:
         first = HEADER_BYTES + 4 * dim * B_local + TERM_BUDGET * B_local
         first = (first + 15) // 16 * 16
         block, total = self._block(q_local, pack_terms(terms_local), B_local, dim, first)
-        if W > 1:
+        if W > 1 or self.always_collect:
             got = torch.empty(W * first, dtype=torch.uint8, device=self.device)
             dist.all_gather_into_tensor(got, block[:first].contiguous(), group=self.group)
             got = got.reshape(W, first)
@@ -153,7 +154,7 @@ class ShardedRecallSearch:
             mine = torch.zeros(rest_max, dtype=torch.uint8, device=self.device)
             if total > first:
                 mine[:total - first] = block[first:total]
-            if W > 1:
+            if W > 1 or self.always_collect:
                 rest = torch.empty(W * rest_max, dtype=torch.uint8, device=self.device)
                 dist.all_gather_into_tensor(rest, mine, group=self.group)
                 rest = rest.reshape(W, rest_max)
@@ -189,13 +190,13 @@ class ShardedRecallSearch:
             dim = int(q.shape[1]) if q is not None and q.numel() else 0
             block, total = self._block(q, pack_terms(terms), B, dim, 0)
             head = torch.tensor([B, dim, total, 0], dtype=torch.int64, device=self.device)
-        if W > 1:
+        if W > 1 or self.always_collect:
             dist.broadcast(head, src=origin, group=self.group)
             self.collectives += 1
         B, dim, total = (int(x) for x in head.cpu()[:3])
         if self.rank != origin:
             block = torch.empty(total, dtype=torch.uint8, device=self.device)
-        if W > 1:
+        if W > 1 or self.always_collect:
             dist.broadcast(block[:total], src=origin, group=self.group)
             self.collectives += 1
         host = self._to_host("queries", block[:total])
@@ -245,7 +246,7 @@ class ShardedRecallSearch:
             self._shard_search(q_sub, t_sub, now_ticks, kprime, candidate_limit, out=mine, mode=mode, topk=k)
             if self._shard_search_done is not None:
                 self._shard_search_done(mine, nb, kprime)
-            if W > 1:
+            if W > 1 or self.always_collect:
                 allrec = torch.empty(W * rec_bytes, dtype=torch.uint8, device=self.device)
                 dist.all_gather_into_tensor(allrec, mine, group=self.group)
                 self.collectives += 1

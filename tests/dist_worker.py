@@ -65,7 +65,7 @@ def oracle_shard_search(P, orc, c, lo, hi):
     return search
 
 
-def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_queries=False):
+def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_queries=False, nccl=False):
     import torch
     import torch.distributed as dist
     import importlib
@@ -75,31 +75,42 @@ def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_querie
     sharded = importlib.import_module(graft.PKG_NAME + ".sharded")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if nccl:        # RCCL itself (one rank per card: on a one-GPU box that is a world of one), collectives on device buffers
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     c = make_corpus(n, dim, seed)
     bounds = [n * r // world for r in range(world + 1)]
     lo, hi = bounds[rank], bounds[rank + 1]
     if use_gpu:      # real shards: every rank keeps its rows on cuda:0 (<= 6 processes may share the card)
         from helpers import build_index
         sub = {"emb": c["emb"][lo:hi], "created": c["created"][lo:hi], "contents": c["contents"][lo:hi], "dim": dim}
-        front = sharded.ShardedRecallSearch(build_index(sub, row_base=lo), dim, "cpu")
+        front = sharded.ShardedRecallSearch(build_index(sub, device=rank if nccl else 0, row_base=lo), dim,
+                                            torch.device("cuda", rank) if nccl else "cpu")
     else:
         front = sharded.ShardedRecallSearch(None, dim, "cpu", shard_search=oracle_shard_search(P, orc, c, lo, hi))
+    front.always_collect = bool(nccl)          # (a world of one issues its collectives too: RCCL on the box's one card)
     rng = np.random.default_rng(100 + rank)
     B_local = 2
     results = []
     texts_all = ["alpha the helm", "kubernetes", "what is the", "GAMMA zzz"]
     for trial, (topk, limit, kprime) in enumerate([(5, n, 8), (10, 300, 4), (3, n, 2), (12, n, 3)]):
         q = torch.from_numpy(rng.standard_normal((B_local, dim)).astype(np.float32))
+        if nccl:
+            q = q.to(front.device)
         texts = [texts_all[(rank * B_local + i + trial) % 4] for i in range(B_local)]
         terms = [P.text.query_terms(t) for t in texts]
         rows, scores, counts = front.search(q, terms, 639144000000000000, topk, limit, kprime=kprime)
         corpus = orc.OracleCorpus(c["emb"], c["created"], c["contents"])
         for i in range(B_local):
-            orow, osc, _ = corpus.search(q[i].numpy(), texts[i], 639144000000000000, topk, candidate_limit=limit)
+            orow, osc, _ = corpus.search(q[i].cpu().numpy(), texts[i], 639144000000000000, topk, candidate_limit=limit)
             ok = list(rows[i, :counts[i]]) == list(orow) and np.array_equal(scores[i, :counts[i]], osc)
             results.append(bool(ok))
     expected = 8
+    if nccl:
+        results.append(bool(front.rccl_ranks_seen() == world))
+        expected += 1
     # ---- queries that cannot be certified in a larger batch: a zero vector without terms scores 0.1 * recency only, so its whole
     # top-3 are the newest rows, all on shard 0, whose k' = 3 cut-off then EQUALS the third best score (and the rows of a
     # document share their timestamp: exact ties across the cut) -> not certified; queries whose top-3 spread over shards are.
@@ -109,7 +120,8 @@ def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_querie
     q4[1] = 0.0
     texts4 = ["alpha the helm", "", "kubernetes", "GAMMA zzz"]
     esc0, escq0 = front.escalations, front.escalated_queries
-    rows, scores, counts = front.search(torch.from_numpy(q4), [P.text.query_terms(t) if t else [] for t in texts4],
+    q4t = torch.from_numpy(q4).to(front.device) if nccl else torch.from_numpy(q4)
+    rows, scores, counts = front.search(q4t, [P.text.query_terms(t) if t else [] for t in texts4],
                                         639144000000000000, 3, n, kprime=3)
     corpus4 = orc.OracleCorpus(c["emb"], c["created"], c["contents"])
     for i in range(B4):
@@ -153,4 +165,5 @@ def run(rank, world, port, n, dim, seed, result_path, use_gpu=False, long_querie
 
 if __name__ == "__main__":
     run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7],
-        use_gpu=len(sys.argv) > 8 and sys.argv[8] == "gpu", long_queries=len(sys.argv) > 9 and sys.argv[9] == "long")
+        use_gpu=len(sys.argv) > 8 and sys.argv[8] in ("gpu", "nccl"), long_queries=len(sys.argv) > 9 and sys.argv[9] == "long",
+        nccl=len(sys.argv) > 8 and sys.argv[8] == "nccl")

@@ -52,6 +52,16 @@ def test_row_sharded_search_real_shards_on_one_gpu(tmp_path):
     _run_world(tmp_path, 3, 3000, 128, extra=("gpu",))
 
 
+@pytest.mark.gpu
+def test_row_sharded_search_over_rccl_with_the_ranks_this_box_has(tmp_path):
+    """The product backend itself: torch.distributed "nccl" (= RCCL), one rank per visible GPU (one on this pool's boxes),
+    queries and the records' all-gather on device buffers -- the branch the gloo rehearsals cannot take.  Results equal the
+    oracle's, the escalation of uncertified queries runs, every rank answers the all-gather."""
+    import torch
+    world = max(1, min(torch.cuda.device_count(), 4))
+    _run_world(tmp_path, world, 3000, 128, extra=("nccl",))
+
+
 def test_term_sections_round_trip():
     """The query exchange carries the ABI's packed term arrays length-prefixed: no per-query or per-term size limit."""
     import importlib
