@@ -2417,6 +2417,11 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
             ORR_TRY(idx->ws_fcnt.reserve(sizeof(uint32_t) * 3 * (size_t)B));      // [survivors][sampled prefix][workgroups done]
             ORR_TRY(idx->ws_fbuf.reserve(sizeof(orr::SelEntry) * (size_t)B * kCap));
             d_tau = idx->ws_tau.as<unsigned long long>();
+            // 0: the prefix's rows are ranked in full; 1: per-lane maxima, sorted; 2: wave maxima, nothing sorted (where 16 per
+            // segment are at least 8 k candidates per query)
+            static const char *prefix_env = getenv("ORR_PREFIX_FULL_RANKING");        // =1: form 0; =2: form 1 (A/B)
+            const int prefix_floor_form = !(two_stage && d_rowc != nullptr) || (prefix_env && atoi(prefix_env) == 1) ? 0
+                                          : ((int64_t)fused_sample_seg * 16 >= 8 * (int64_t)std::max<int32_t>(1, a.topk) && !(prefix_env && atoi(prefix_env) == 2)) ? 2 : 1;
             if (!ts_gemv) {
                 Timed t(idx, "fuse_select", (double)B * (double)dotf_rows * 28.0);
                 orr::I8Prefix i8p;
@@ -2426,7 +2431,7 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                                                 std::min<int64_t>(dotf_rows, n), B, 0, fused_sample_seg, nullptr, idx->ws_sel.as<orr::SelEntry>(),
                                                 lists_total, s, i8p,
                                                 // two-stage: the prefix only yields the floor (the records come out of the survivors' buffers)
-                                                two_stage && d_rowc != nullptr && !getenv("ORR_PREFIX_FULL_RANKING")));
+                                                prefix_floor_form));
             }
             ORR_TRY(idx->ws_fqf.reserve(sizeof(float4) * 2 * (size_t)B));
             orr::FusedEpilogue epi{};
@@ -2528,7 +2533,8 @@ int run_shard_once(orr_index *idx, const BatchArgs &a, int32_t kprime, bool host
                     }
                 } else {
                     Timed t(idx, "select_floor", 0.0);
-                    HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kth, d_tau, s, floor));
+                    HIP_TRY(orr::launch_select_final_sample(idx->ws_sel.as<orr::SelEntry>(), lists_total, fused_sample_seg, B, kth, d_tau, s, floor,
+                                                            prefix_floor_form == 2 ? 1 : 0));
                 }
                 // the screening GEMM runs on the int8 shadow where there is one (K2j), else on the bf16 shadow (K2c),
                 // else it converts the fp32 rows itself

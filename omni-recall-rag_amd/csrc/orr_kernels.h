@@ -184,7 +184,8 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
                               SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8 = I8Prefix(),
-                              bool floor_only = false);     // floor_only: lists of per-lane maxima (enough for a floor key; FAST rows, no tau)
+                              int floor_only = 0);          // floor_only 1: lists of per-lane maxima (enough for a floor key; FAST rows, no tau);
+                                                            // 2: 16 wave maxima per list, nothing sorted (launch_select_final_sample wave_maxima = 1)
 
 // K5b: merges the per-workgroup lists of each query and writes kprime candidate
 // records plus the trailer ([B][kprime+1], see orr_candidate).
@@ -314,7 +315,8 @@ struct FloorOut {
     double eps3 = 0.0, eps1 = 0.0;
 };
 hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
-                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor = FloorOut());
+                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor = FloorOut(),
+                                      int32_t wave_maxima = 0);    // 1: the lists hold 16 unsorted wave maxima each (fuse_select floor_only = 2)
 
 // Generic path for large k: keys[r] = score key of (query b,row r), vals[r] = r.
 hipError_t launch_score_keys(const double *dot, const double *norm_b, const int64_t *created,

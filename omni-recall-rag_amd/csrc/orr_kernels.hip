@@ -633,7 +633,10 @@ hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *count
 // and the wave's list is ONE sort of those -- the k-th best of such maxima belongs to k distinct rows, so it is a valid floor,
 // and with thousands of lanes per query it is the k-th best row's key itself unless two of the k best rows share a lane
 // (k^2 / (2 x 13,000) of the time at 10M rows): a quarter of the sorts and none of the merges of the full ranking.
-template <bool FAST, bool LANEMAX>
+// LANEMAX = 2 (enough segments for 8 k wave maxima per query): nothing is sorted at all -- every wave writes the best of its 256 rows
+// into slot `wave` of the segment's list (16 entries per list, the rest unused), and the floor is the k-th best of those
+// (select_floor_heads_kernel with 16 entries per list).
+template <bool FAST, int LANEMAX>
 __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restrict__ dot,
                                                            const float *__restrict__ dotf, int64_t dot_stride,
                                                            const double *__restrict__ norm_b,
@@ -700,10 +703,24 @@ __global__ __launch_bounds__(1024) void fuse_select_kernel(const double *__restr
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (better(nk[u], np[u], k, p)) { k = nk[u]; p = np[u]; }
+        if (LANEMAX == 2) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const unsigned long long ok = __shfl_xor(k, d, 64);
+                const uint32_t op = __shfl_xor(p, d, 64);
+                if (better(ok, op, k, p)) { k = ok; p = op; }
+            }
+            if (lane == 0) {
+                SelEntry e;
+                e.key = k; e.pos = p; e.pad = 0;
+                out_sel[((int64_t)b * n_seg_total + seg) * kSelWidth + wave] = e;
+            }
+            return;
+        }
         wave_sort(k, p, lane);
     }
 #pragma unroll
-    for (int u = 0; u < U && !LANEMAX; ++u) {
+    for (int u = 0; u < U && LANEMAX == 0; ++u) {
         if (seg0 + (int64_t)(wave * U + u) * 64 >= seg1) break;
         if (floor_key) {
             if (!__any(nk[u] > floor_key)) continue;
@@ -738,20 +755,23 @@ hipError_t launch_fuse_select(const double *dot, const float *dotf, int64_t dot_
                               const int64_t *created, const double2 *row_consts, KwView kw,
                               const QueryConst *qc, int64_t now_ticks, int64_t n_rows, int32_t B,
                               int32_t seg_first, int32_t seg_count, const unsigned long long *tau,
-                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8, bool floor_only)
+                              SelEntry *out_sel, int32_t n_seg_stride, hipStream_t s, I8Prefix i8, int floor_only)
 {
     if (n_rows <= 0 || B <= 0 || seg_count <= 0) return hipSuccess;
     const int64_t n_seg = n_seg_stride > 0 ? n_seg_stride : (n_rows + kSelSegRows - 1) / kSelSegRows;
     if (n_seg > 65535) return hipErrorInvalidValue;
     if (floor_only && (tau || !row_consts)) return hipErrorInvalidValue;
-    if (floor_only)
-        hipLaunchKernelGGL((fuse_select_kernel<true, true>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
+    if (floor_only == 2)
+        hipLaunchKernelGGL((fuse_select_kernel<true, 2>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
+                           norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel, i8);
+    else if (floor_only)
+        hipLaunchKernelGGL((fuse_select_kernel<true, 1>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
                            norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel, i8);
     else if (row_consts)
-        hipLaunchKernelGGL((fuse_select_kernel<true, false>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
+        hipLaunchKernelGGL((fuse_select_kernel<true, 0>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
                            norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel, i8);
     else
-        hipLaunchKernelGGL((fuse_select_kernel<false, false>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
+        hipLaunchKernelGGL((fuse_select_kernel<false, 0>), dim3((unsigned)B, (unsigned)seg_count), dim3(1024), 0, s, dot, dotf, dot_stride,
                            norm_b, created, row_consts, kw, qc, now_ticks, n_rows, seg_first, (int32_t)n_seg, tau, out_sel, I8Prefix());
     return hipGetLastError();
 }
@@ -855,14 +875,16 @@ hipError_t launch_select_final(const SelEntry *sel, int32_t n_seg, int32_t B, in
 // k distinct rows, so it is a valid floor, and it is the k-th best row's key unless two of the k best rows share a list
 // (k^2 / (2 lists) of the time: the floor is then the (k+1)-th best).  One wave per query instead of sixteen merging every list.
 __global__ __launch_bounds__(64) void select_floor_heads_kernel(const SelEntry *__restrict__ sel, int32_t n_seg, int32_t seg_stride,
-                                                                int32_t kprime, unsigned long long *__restrict__ tau_out, FloorOut floor)
+                                                                int32_t kprime, unsigned long long *__restrict__ tau_out, FloorOut floor,
+                                                                int32_t per_list)
 {
     const int lane = threadIdx.x, b = blockIdx.x;
     const SelEntry *mine = sel + (int64_t)b * seg_stride * kSelWidth;
     unsigned long long k = 0ull;
     uint32_t p = 0xFFFFFFFFu;
-    for (int sg = lane; sg < n_seg; sg += 64) {
-        const SelEntry e = mine[(int64_t)sg * kSelWidth];
+    // per_list = 1: the heads of sorted lists; 16: the 16 wave maxima a floor-only ranking left in each list's first slots
+    for (int i = lane; i < n_seg * per_list; i += 64) {
+        const SelEntry e = mine[(int64_t)(i / per_list) * kSelWidth + (i % per_list)];
         if (better(e.key, e.pos, k, p)) { k = e.key; p = e.pos; }
     }
     wave_sort(k, p, lane);
@@ -874,13 +896,18 @@ __global__ __launch_bounds__(64) void select_floor_heads_kernel(const SelEntry *
 }
 
 hipError_t launch_select_final_sample(const SelEntry *sel, int32_t n_seg_total, int32_t sample_seg, int32_t B,
-                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor)
+                                      int32_t kprime, unsigned long long *tau_out, hipStream_t s, FloorOut floor, int32_t wave_maxima)
 {
     if (B <= 0 || sample_seg <= 0) return hipSuccess;
     if (kprime < 1 || kprime > kSelWidth) return hipErrorInvalidValue;
+    if (wave_maxima) {                                                 // (the lists hold 16 wave maxima each: fuse_select's LANEMAX = 2)
+        if (!floor.floor_key) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(select_floor_heads_kernel, dim3((unsigned)B), dim3(64), 0, s, sel, sample_seg, n_seg_total, kprime, tau_out, floor, 16);
+        return hipGetLastError();
+    }
     static const bool full = getenv("ORR_FLOOR_FULL") != nullptr;      // (A/B)
     if (floor.floor_key && sample_seg >= 8 * kprime && !full) {        // (a two-stage pass's floor: any k distinct rows' k-th key serves)
-        hipLaunchKernelGGL(select_floor_heads_kernel, dim3((unsigned)B), dim3(64), 0, s, sel, sample_seg, n_seg_total, kprime, tau_out, floor);
+        hipLaunchKernelGGL(select_floor_heads_kernel, dim3((unsigned)B), dim3(64), 0, s, sel, sample_seg, n_seg_total, kprime, tau_out, floor, 1);
         return hipGetLastError();
     }
     const KwView nokw{nullptr, 0, nullptr, nullptr};
