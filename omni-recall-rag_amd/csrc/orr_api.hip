@@ -168,6 +168,7 @@ struct orr_index {
     // vocabulary tokens longer than 16 bytes (URLs and the like) go through the wave-per-token scan; the rest is
     // matched one lane per token.  Built at the first search with terms (ensure_vlong); -1 = not yet.
     int64_t n_vlong = -1;
+    int64_t n_vmid = 0;                // the first n_vmid entries of the list are the tokens of 17..32 bytes (one lane per token too)
     DevBuf vlong_start, vlong_len, vlong_id;
     // stored row bitmaps of the FREQUENT vocabulary tokens (a posting list of at least rows / 64 entries: the bitmap is at most
     // twice its bytes), built at the first search with terms over a large shard (ensure_token_bitmaps): a query term whose only
@@ -1206,8 +1207,11 @@ static int ensure_vlong(orr_index *idx)
         HIP_TRY(hipMemcpy(vstart.data(), idx->d_vstart, sizeof(uint64_t) * V, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(vlen.data(), idx->d_vlen, sizeof(uint32_t) * V, hipMemcpyDeviceToHost));
     }
-    for (size_t v = 0; v < V; ++v)
-        if (vlen[v] > 16) { start.push_back(vstart[v]); len.push_back(vlen[v]); id.push_back((uint32_t)v); }
+    for (int pass = 0; pass < 2; ++pass) {                         // 17..32 bytes first, the longer ones behind them
+        for (size_t v = 0; v < V; ++v)
+            if (vlen[v] > 16 && (vlen[v] <= 32) == (pass == 0)) { start.push_back(vstart[v]); len.push_back(vlen[v]); id.push_back((uint32_t)v); }
+        if (pass == 0) idx->n_vmid = (int64_t)id.size();
+    }
     if (!id.empty()) {
         ORR_TRY(idx->vlong_start.reserve(sizeof(uint64_t) * id.size()));
         ORR_TRY(idx->vlong_len.reserve(sizeof(uint32_t) * id.size()));
@@ -1535,6 +1539,7 @@ static int make_view(orr_index *parent, orr_index **out, bool internal)
     if (!v) return fail(ORR_ENOMEM, "out of host memory");
     v->is_view = true;
     v->n_vlong = parent->n_vlong;
+    v->n_vmid = parent->n_vmid;
     v->n_tok_bm = parent->n_tok_bm; v->tok_bm_words = parent->tok_bm_words;
     v->tok_bm.p = parent->tok_bm.p; v->tok_bm_index.p = parent->tok_bm_index.p;                                        // borrowed
     v->vlong_start.p = parent->vlong_start.p; v->vlong_len.p = parent->vlong_len.p; v->vlong_id.p = parent->vlong_id.p;   // borrowed
@@ -1841,7 +1846,8 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
         const size_t off_qmeta = off_terms + sizeof(orr::ScanTerm) * TT;
         const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
         const size_t off_match = off_iota + sizeof(uint32_t) * 65;
-        const size_t off_pool = off_match + sizeof(orr::MatchTerm) * TT;
+        const size_t off_match8 = off_match + sizeof(orr::MatchTerm) * TT;
+        const size_t off_pool = off_match8 + sizeof(orr::MatchTerm8) * TT;
         const size_t meta_bytes = off_pool + pool_bytes + 16;
         ORR_TRY(idx->pin_meta.reserve(meta_bytes));
         ORR_TRY(idx->ws_meta.reserve(meta_bytes));
@@ -1864,6 +1870,13 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
             for (uint32_t k = 0; k < 16 && k < st[t].len; ++k) {
                 mt.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
                 mt.m[k >> 2] |= 0xFFu << (8 * (k & 3));
+            }
+            orr::MatchTerm8 &m8 = reinterpret_cast<orr::MatchTerm8 *>(hm + off_match8)[t];
+            memset(&m8, 0, sizeof(m8));
+            m8.len = st[t].len;
+            for (uint32_t k = 0; k < 32 && k < st[t].len; ++k) {
+                m8.w[k >> 2] |= (uint32_t)(uint8_t)dterms[t][k] << (8 * (k & 3));
+                m8.m[k >> 2] |= 0xFFu << (8 * (k & 3));
             }
             memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
             cursor += st[t].len;
@@ -1920,16 +1933,28 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
                                                       reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
                                                       idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
             }
-            if (VL > 0) {   // longer tokens: every distinct term is its own 1-term "query" of the wave-per-token scan
+            // tokens of 17..32 bytes (the front of the list of longer tokens): one lane per token as well (ORR_VOCAB_MID=0: through
+            // the wave-per-token scan like the longer ones, A/B)
+            static const bool mid_off = [] { const char *e = getenv("ORR_VOCAB_MID"); return e && atoi(e) == 0; }();
+            const int64_t n_mid = mid_off ? 0 : std::min<int64_t>(idx->n_vmid, VL);
+            if (n_mid > 0) {
+                Timed t(idx, "vocab_match_mid", 0.0, k);
+                HIP_TRY(orr::launch_vocab_match_mid(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(),
+                                                    idx->vlong_id.as<uint32_t>(), n_mid, reinterpret_cast<const orr::MatchTerm8 *>(dm + off_match8),
+                                                    (int32_t)TT, idx->d_post_off, idx->ws_counter.as<unsigned long long>(),
+                                                    idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+            }
+            if (VL - n_mid > 0) {   // the rest: every distinct term is its own 1-term "query" of the wave-per-token scan
+                const int64_t VS = VL - n_mid;
                 {
                     Timed t(idx, "vocab_scan", 0.0, k);
-                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>(), idx->vlong_len.as<uint32_t>(), VL,
+                    HIP_TRY(orr::launch_vocab_scan(idx->d_vpool, idx->vlong_start.as<uint64_t>() + n_mid, idx->vlong_len.as<uint32_t>() + n_mid, VS,
                                                    dm + off_pool, d_terms, (int32_t)TT, reinterpret_cast<const uint32_t *>(dm + off_iota),
                                                    idx->ws_vmatch.as<uint16_t>(), k));
                 }
                 {
                     Timed t(idx, "vocab_hits", 0.0, k);
-                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VL, (int32_t)TT, idx->vlong_id.as<uint32_t>(), idx->d_post_off,
+                    HIP_TRY(orr::launch_vocab_hits(idx->ws_vmatch.as<uint16_t>(), VS, (int32_t)TT, idx->vlong_id.as<uint32_t>() + n_mid, idx->d_post_off,
                                                    idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
                 }
             }

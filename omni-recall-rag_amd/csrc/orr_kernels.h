@@ -130,11 +130,21 @@ struct MatchTerm {
     uint32_t len;       // bytes; terms longer than 16 bytes cannot occur in the tokens this kernel covers
     uint32_t pad[3];
 };
+struct MatchTerm8 {                   // the same with eight dwords: terms of up to 32 bytes against tokens of 17..32 bytes
+    uint32_t w[8], m[8];
+    uint32_t len;
+    uint32_t pad[3];
+};
 constexpr int kMatchGroup = 32;       // terms per workgroup (grid.y)
 // Every token of at most 16 bytes against every term, hits reserved as by launch_vocab_hits.
 hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
                                     const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
                                     unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
+// The tokens of 17..32 bytes of a list (start, length, token number) against every term (longer terms cannot occur in them),
+// one lane per token.
+hipError_t launch_vocab_match_mid(const uint8_t *vpool, const uint64_t *starts, const uint32_t *lens, const uint32_t *ids, int64_t n_list,
+                                  const MatchTerm8 *terms, int32_t n_terms, const uint64_t *post_off, unsigned long long *counter,
+                                  KwHit *hits, uint32_t max_hits, hipStream_t s);
 // counter_host (optional, pinned host memory): receives *counter (hits << 32 | chunks) for the caller's statistics.
 // skip_term (optional, [terms]): hits of terms flagged there are left out (their bitmaps are aliases, launch_kw_alias).
 hipError_t launch_expand_hits(const KwHit *hits, const unsigned long long *counter, uint32_t max_hits,

@@ -601,6 +601,84 @@ __global__ __launch_bounds__(256) void vocab_match_short_kernel(const uint8_t *_
     }
 }
 
+// The same for tokens of 17..32 bytes, given as a list (start, length, token number): 32 windows per lane, terms of up to 32
+// bytes (eight dwords); longer terms cannot occur in these tokens.
+__global__ __launch_bounds__(256) void vocab_match_mid_kernel(const uint8_t *__restrict__ vpool, const uint64_t *__restrict__ starts,
+                                                              const uint32_t *__restrict__ lens, const uint32_t *__restrict__ ids,
+                                                              int64_t n_list, const MatchTerm8 *__restrict__ terms, int32_t n_terms,
+                                                              const uint64_t *__restrict__ post_off, unsigned long long *__restrict__ counter,
+                                                              KwHit *__restrict__ hits, uint32_t max_hits)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int32_t t0 = (int32_t)blockIdx.y * kMatchGroup;
+    const int32_t t1 = n_terms < t0 + kMatchGroup ? n_terms : t0 + kMatchGroup;
+    int32_t len = 0;
+    uint32_t v = 0u;
+    uint32_t w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = 0x20202020u;
+    if (i < n_list) {
+        const uint32_t l = lens[i];
+        if (l >= 17 && l <= 32) {
+            len = (int32_t)l;
+            v = ids[i];
+            const uint4 a = *reinterpret_cast<const uint4 *>(vpool + starts[i]);            // rows start 16-byte aligned; a token
+            const uint4 b = *reinterpret_cast<const uint4 *>(vpool + starts[i] + 16);       // of 17..32 bytes owns at least 32
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        }
+    }
+    uint32_t win[32];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        win[4 * k] = w[k];
+        win[4 * k + 1] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], 1);
+        win[4 * k + 2] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], 2);
+        win[4 * k + 3] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], 3);
+    }
+    for (int32_t t = t0; t < t1; ++t) {
+        const uint32_t tlen = (uint32_t)uniform32((int)terms[t].len);
+        if (tlen == 0 || tlen > 32) continue;
+        const uint32_t w0 = (uint32_t)uniform32((int)terms[t].w[0]), m0 = (uint32_t)uniform32((int)terms[t].m[0]);
+        uint32_t cand = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) cand |= ((win[k] & m0) == w0) ? (1u << k) : 0u;
+        const int32_t last = len - (int32_t)tlen;                 // last start that keeps the term inside the token (<= 31)
+        cand = last < 0 ? 0u : (cand & ((2u << last) - 1u));
+        if (__ballot(cand != 0u) == 0ull) continue;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            if (tlen <= 4u * j) break;
+            const uint32_t wj = (uint32_t)uniform32((int)terms[t].w[j]), mj = (uint32_t)uniform32((int)terms[t].m[j]);
+#pragma unroll
+            for (int k = 0; k + 4 * j < 32; ++k)
+                if ((win[k + 4 * j] & mj) != wj) cand &= ~(1u << k);
+        }
+        if (cand == 0u) continue;
+        const uint64_t p0 = post_off[v], p1 = post_off[v + 1];
+        const uint32_t chunks = (uint32_t)((p1 - p0 + kPostChunk - 1) / kPostChunk);
+        const unsigned long long old = atomicAdd(counter, (1ull << 32) | chunks);
+        const uint32_t slot = (uint32_t)(old >> 32);
+        if (slot < max_hits) {
+            KwHit h;
+            h.post_begin = p0; h.post_len = (uint32_t)(p1 - p0); h.chunk_base = (uint32_t)old; h.term = (uint32_t)t; h.token = v;
+            hits[slot] = h;
+        }
+    }
+}
+
+hipError_t launch_vocab_match_mid(const uint8_t *vpool, const uint64_t *starts, const uint32_t *lens, const uint32_t *ids, int64_t n_list,
+                                  const MatchTerm8 *terms, int32_t n_terms, const uint64_t *post_off, unsigned long long *counter,
+                                  KwHit *hits, uint32_t max_hits, hipStream_t s)
+{
+    if (n_list <= 0 || n_terms <= 0) return hipSuccess;
+    const int64_t blocks = (n_list + 255) / 256;
+    const int32_t groups = (n_terms + kMatchGroup - 1) / kMatchGroup;
+    if (groups > 65535 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vocab_match_mid_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, s, vpool, starts, lens, ids, n_list,
+                       terms, n_terms, post_off, counter, hits, max_hits);
+    return hipGetLastError();
+}
+
 hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
                                     const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
                                     unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s)
