@@ -1847,8 +1847,12 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
         const size_t off_iota = off_qmeta + sizeof(uint32_t) * qmeta.size();
         const size_t off_match = off_iota + sizeof(uint32_t) * 65;
         const size_t off_match8 = off_match + sizeof(orr::MatchTerm) * TT;
-        const size_t off_pool = off_match8 + sizeof(orr::MatchTerm8) * TT;
-        const size_t meta_bytes = off_pool + pool_bytes + 16;
+        const size_t off_lk = off_match8 + sizeof(orr::MatchTerm8) * TT;       // [8 u32 class boundaries][TT keys][TT term numbers]
+        const size_t off_pool = off_lk + sizeof(uint32_t) * (8 + 2 * (size_t)TT);
+        const size_t off_bloom = (off_pool + pool_bytes + 16 + 15) / 16 * 16;   // (last: only uploaded when the lookup form runs)
+        const bool vocab_lookup = [&] { static const int e = [] { const char *v = getenv("ORR_VOCAB_LOOKUP"); return v ? atoi(v) : -1; }();
+                                        return e >= 0 ? e != 0 : TT >= 64; }();
+        const size_t meta_bytes = vocab_lookup ? off_bloom + orr::kVocabBloomBits / 8 : off_pool + pool_bytes + 16;
         ORR_TRY(idx->pin_meta.reserve(meta_bytes));
         ORR_TRY(idx->ws_meta.reserve(meta_bytes));
         uint8_t *hm = idx->pin_meta.as<uint8_t>();
@@ -1880,6 +1884,32 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
             }
             memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
             cursor += st[t].len;
+        }
+        {   // the terms of at most 16 bytes sorted by (class = min(bytes, 4), length-masked first dword): vocab_match_lookup
+            uint32_t *lk = reinterpret_cast<uint32_t *>(hm + off_lk), *keys = lk + 8, *tix = keys + TT;
+            const orr::MatchTerm *mts = reinterpret_cast<const orr::MatchTerm *>(hm + off_match);
+            std::vector<std::pair<uint64_t, uint32_t>> order;
+            order.reserve(TT);
+            for (uint32_t t = 0; t < TT; ++t)
+                if (st[t].len >= 1 && st[t].len <= 16)
+                    order.emplace_back(((uint64_t)(std::min<uint32_t>(st[t].len, 4u) - 1u) << 32) | mts[t].w[0], t);
+            std::sort(order.begin(), order.end());
+            for (int c = 0; c <= 4; ++c) lk[c] = 0;
+            for (size_t i = 0; i < order.size(); ++i) {
+                keys[i] = (uint32_t)order[i].first;
+                tix[i] = order[i].second;
+                lk[(order[i].first >> 32) + 1] = (uint32_t)i + 1;
+            }
+            for (int c = 1; c <= 4; ++c) lk[c] = std::max(lk[c], lk[c - 1]);     // empty classes inherit the boundary in front of them
+            lk[5] = lk[6] = lk[7] = 0;
+            if (vocab_lookup) {
+                uint32_t *bloom = reinterpret_cast<uint32_t *>(hm + off_bloom);
+                memset(bloom, 0, orr::kVocabBloomBits / 8);
+                for (const auto &o : order) {
+                    const uint32_t hb = orr::vocab_bloom_hash((uint32_t)o.first, (uint32_t)(o.first >> 32));
+                    bloom[hb >> 5] |= 1u << (hb & 31u);
+                }
+            }
         }
         memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
         uint32_t *iota = reinterpret_cast<uint32_t *>(hm + off_iota);
@@ -1927,11 +1957,20 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
         };
         if (V > 0) {
             const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
-            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place
+            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place; from 64 terms
+                // on the terms are looked up (sorted by first dword) instead of compared one by one (ORR_VOCAB_LOOKUP=0|1 forces either)
                 Timed t(idx, "vocab_match", 0.0, k);
-                HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
-                                                      reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
-                                                      idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+                if (vocab_lookup) {
+                    const uint32_t *lk = reinterpret_cast<const uint32_t *>(dm + off_lk);
+                    HIP_TRY(orr::launch_vocab_match_lookup(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
+                                                           reinterpret_cast<const orr::MatchTerm *>(dm + off_match), lk, lk + 8, lk + 8 + TT,
+                                                           reinterpret_cast<const uint32_t *>(dm + off_bloom), idx->d_post_off,
+                                                           idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+                } else {
+                    HIP_TRY(orr::launch_vocab_match_short(idx->d_vpool, idx->d_vstart, idx->d_vlen, V,
+                                                          reinterpret_cast<const orr::MatchTerm *>(dm + off_match), (int32_t)TT, idx->d_post_off,
+                                                          idx->ws_counter.as<unsigned long long>(), idx->ws_hits.as<orr::KwHit>(), max_hits, k));
+                }
             }
             // tokens of 17..32 bytes (the front of the list of longer tokens): one lane per token as well (ORR_VOCAB_MID=0: through
             // the wave-per-token scan like the longer ones, A/B)

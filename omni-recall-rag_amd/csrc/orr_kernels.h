@@ -140,6 +140,23 @@ constexpr int kMatchGroup = 32;       // terms per workgroup (grid.y)
 hipError_t launch_vocab_match_short(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
                                     const MatchTerm *terms, int32_t n_terms, const uint64_t *post_off,
                                     unsigned long long *counter, KwHit *hits, uint32_t max_hits, hipStream_t s);
+// Tokens of at most 16 bytes against MANY terms: the terms (of at most 16 bytes) sorted by their length-masked first dword in
+// four classes (lk[0..4] = class boundaries in keys / tidx; 1, 2, 3, 4+ bytes), every window of a token looked up.
+// bloom: kVocabBloomBits bits, bit vocab_bloom_hash(key, class) set for every (class, key) of the tables.
+constexpr int kVocabBloomBits = 1 << 17;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t vocab_bloom_hash(uint32_t key, uint32_t cls)
+{
+    uint32_t h = (key ^ (cls * 0x9E3779B9u)) * 2654435761u;
+    h ^= h >> 15;
+    return h & (uint32_t)(kVocabBloomBits - 1);
+}
+hipError_t launch_vocab_match_lookup(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
+                                     const MatchTerm *terms, const uint32_t *lk, const uint32_t *keys, const uint32_t *tidx,
+                                     const uint32_t *bloom, const uint64_t *post_off, unsigned long long *counter, KwHit *hits,
+                                     uint32_t max_hits, hipStream_t s);
 // The tokens of 17..32 bytes of a list (start, length, token number) against every term (longer terms cannot occur in them),
 // one lane per token.
 hipError_t launch_vocab_match_mid(const uint8_t *vpool, const uint64_t *starts, const uint32_t *lens, const uint32_t *ids, int64_t n_list,

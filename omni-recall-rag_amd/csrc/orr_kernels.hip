@@ -601,6 +601,141 @@ __global__ __launch_bounds__(256) void vocab_match_short_kernel(const uint8_t *_
     }
 }
 
+// Many terms (a batch of 256+ queries against a vocabulary of 10^5..10^6 tokens): the all-pairs form above costs tokens x terms
+// first-dword compares.  Here the terms are LOOKED UP instead: the host sorts them by their (length-masked) first dword in four
+// classes -- 1, 2, 3 and 4+ bytes -- and a lane searches each of its token's 16 windows in each non-empty class (binary search,
+// then the run of equal keys), verifying the few candidates like the all-pairs form does.  One hit per (token, term): a start
+// only counts if no earlier start of the token matches the term too.
+//   lk[0..4] = class boundaries in keys / tidx (class c holds the terms of c + 1 bytes, class 3 those of 4..16 bytes).
+__device__ __forceinline__ bool term_at(const uint32_t (&win)[16], int i, const MatchTerm &mt)
+{
+    // (bytes behind the token are spaces, which no term contains: a start too close to the end fails by itself)
+    bool ok = (win[i] & mt.m[0]) == mt.w[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (mt.len > 4u * j) {
+            const uint32_t wv = i + 4 * j < 16 ? win[(i + 4 * j) & 15] : 0x20202020u;
+            ok = ok && (wv & mt.m[j]) == mt.w[j];
+        }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void vocab_match_lookup_kernel(const uint8_t *__restrict__ vpool, const uint64_t *__restrict__ vstart,
+                                                                 const uint32_t *__restrict__ vlen, int64_t n_tokens,
+                                                                 const MatchTerm *__restrict__ terms, const uint32_t *__restrict__ lk,
+                                                                 const uint32_t *__restrict__ keys, const uint32_t *__restrict__ tidx,
+                                                                 const uint32_t *__restrict__ bloom,
+                                                                 const uint64_t *__restrict__ post_off, unsigned long long *__restrict__ counter,
+                                                                 KwHit *__restrict__ hits, uint32_t max_hits)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int32_t len = 0;
+    uint4 w = make_uint4(0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u);
+    if (v < n_tokens) {
+        const uint32_t l = vlen[v];
+        if (l >= 1 && l <= 16) { len = (int32_t)l; w = *reinterpret_cast<const uint4 *>(vpool + vstart[v]); }   // rows start 16-byte aligned
+    }
+    const uint32_t w4 = 0x20202020u;
+    uint32_t win[16];
+    win[0] = w.x;  win[1] = __builtin_amdgcn_alignbyte(w.y, w.x, 1);
+    win[2] = __builtin_amdgcn_alignbyte(w.y, w.x, 2);  win[3] = __builtin_amdgcn_alignbyte(w.y, w.x, 3);
+    win[4] = w.y;  win[5] = __builtin_amdgcn_alignbyte(w.z, w.y, 1);
+    win[6] = __builtin_amdgcn_alignbyte(w.z, w.y, 2);  win[7] = __builtin_amdgcn_alignbyte(w.z, w.y, 3);
+    win[8] = w.z;  win[9] = __builtin_amdgcn_alignbyte(w.w, w.z, 1);
+    win[10] = __builtin_amdgcn_alignbyte(w.w, w.z, 2); win[11] = __builtin_amdgcn_alignbyte(w.w, w.z, 3);
+    win[12] = w.w; win[13] = __builtin_amdgcn_alignbyte(w4, w.w, 1);
+    win[14] = __builtin_amdgcn_alignbyte(w4, w.w, 2);  win[15] = __builtin_amdgcn_alignbyte(w4, w.w, 3);
+    // a Bloom filter of the (class, key) pairs in LDS (built by the host, kVocabBloomBits bits): sixteen independent reads per class
+    // instead of sixteen binary searches of dependent loads; a window goes to the search only when its bit is set
+    __shared__ uint32_t bloom_lds[kVocabBloomBits / 32];
+    // The hits of a workgroup are staged in LDS and reserved in the global list with ONE atomic (hit slots and posting chunks come
+    // out of one 64-bit counter and must stay jointly ascending: expand_hits searches the list by chunk number): a batch of 256
+    // queries against 250,000 tokens leaves 23,000 hits, and as many atomics on one address were the whole cost of the all-pairs
+    // form (0.27 ms of which 0.02 is comparing).
+    constexpr uint32_t kStage = 512;
+    __shared__ KwHit staged[kStage];
+    __shared__ unsigned long long local_ctr, base_ctr;
+    for (int i = threadIdx.x; i < kVocabBloomBits / 32; i += 256) bloom_lds[i] = bloom[i];
+    if (threadIdx.x == 0) local_ctr = 0ull;
+    __syncthreads();
+    if (len != 0) {
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {                                 // (not unrolled: sixteen copies of the search are code enough)
+        const uint32_t c0 = lk[c], c1 = lk[c + 1];
+        if (c0 == c1) continue;                                   // (uniform: no term of this class in the batch)
+        const uint32_t mask = c == 0 ? 0xFFu : c == 1 ? 0xFFFFu : c == 2 ? 0xFFFFFFu : 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i + c + 1 > len) continue;                        // the shortest term of this class does not fit behind this start
+            const uint32_t key = win[i] & mask;
+            const uint32_t hb = vocab_bloom_hash(key, (uint32_t)c);
+            if (!((bloom_lds[hb >> 5] >> (hb & 31u)) & 1u)) continue;
+            uint32_t lo = c0, hi = c1;                            // lower bound of key in keys[c0, c1)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            for (uint32_t pos = lo; pos < c1 && keys[pos] == key; ++pos) {
+                const uint32_t t = tidx[pos];
+                const MatchTerm mt = terms[t];
+                if ((int32_t)mt.len > len - i) continue;          // the term would run past the token's end
+                if (!term_at(win, i, mt)) continue;
+                bool earlier = false;                             // one hit per (token, term)
+                for (int e = 0; e < i; ++e) earlier = earlier || term_at(win, e, mt);
+                if (earlier) continue;
+                const uint64_t p0 = post_off[v], p1 = post_off[v + 1];
+                const uint32_t chunks = (uint32_t)((p1 - p0 + kPostChunk - 1) / kPostChunk);
+                KwHit h;
+                h.post_begin = p0; h.post_len = (uint32_t)(p1 - p0); h.term = t; h.token = (uint32_t)v;
+                const unsigned long long mine = atomicAdd(&local_ctr, (1ull << 32) | chunks);
+                if ((uint32_t)(mine >> 32) < kStage) {
+                    h.chunk_base = (uint32_t)mine;                // (relative to the workgroup's block: rebased below)
+                    staged[(uint32_t)(mine >> 32)] = h;
+                } else {                                          // (more hits than the stage holds: straight into the list)
+                    const unsigned long long old = atomicAdd(counter, (1ull << 32) | chunks);
+                    const uint32_t slot = (uint32_t)(old >> 32);
+                    h.chunk_base = (uint32_t)old;
+                    if (slot < max_hits) hits[slot] = h;
+                }
+            }
+        }
+    }
+    }
+    __syncthreads();
+    // the staged hits: everything up to the first one that did not fit (hits and chunks counted in the order of the local counter)
+    const uint32_t n_local = (uint32_t)(local_ctr >> 32) < kStage ? (uint32_t)(local_ctr >> 32) : kStage;
+    if (n_local == 0) return;
+    if (threadIdx.x == 0) {
+        // chunks of the staged hits = the local chunk counter where hit number n_local began (or the total when all fit)
+        uint32_t staged_chunks = (uint32_t)local_ctr;
+        if ((uint32_t)(local_ctr >> 32) > kStage) {
+            const KwHit &last = staged[kStage - 1];
+            staged_chunks = last.chunk_base + (uint32_t)((last.post_len + kPostChunk - 1) / kPostChunk);
+        }
+        base_ctr = atomicAdd(counter, ((unsigned long long)n_local << 32) | staged_chunks);
+    }
+    __syncthreads();
+    const uint32_t base_slot = (uint32_t)(base_ctr >> 32), base_chunk = (uint32_t)base_ctr;
+    for (uint32_t i = threadIdx.x; i < n_local; i += 256) {
+        KwHit h = staged[i];
+        h.chunk_base += base_chunk;
+        if (base_slot + i < max_hits) hits[base_slot + i] = h;
+    }
+}
+
+hipError_t launch_vocab_match_lookup(const uint8_t *vpool, const uint64_t *vstart, const uint32_t *vlen, int64_t n_tokens,
+                                     const MatchTerm *terms, const uint32_t *lk, const uint32_t *keys, const uint32_t *tidx,
+                                     const uint32_t *bloom, const uint64_t *post_off, unsigned long long *counter, KwHit *hits,
+                                     uint32_t max_hits, hipStream_t s)
+{
+    if (n_tokens <= 0) return hipSuccess;
+    const int64_t blocks = (n_tokens + 255) / 256;
+    if (blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vocab_match_lookup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, vpool, vstart, vlen, n_tokens, terms, lk, keys, tidx,
+                       bloom, post_off, counter, hits, max_hits);
+    return hipGetLastError();
+}
+
 // The same for tokens of 17..32 bytes, given as a list (start, length, token number): 32 windows per lane, terms of up to 32
 // bytes (eight dwords); longer terms cannot occur in these tokens.
 __global__ __launch_bounds__(256) void vocab_match_mid_kernel(const uint8_t *__restrict__ vpool, const uint64_t *__restrict__ starts,
