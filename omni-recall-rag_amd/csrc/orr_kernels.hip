@@ -485,12 +485,20 @@ __global__ __launch_bounds__(256) void expand_hits_kernel(const KwHit *__restric
     const uint32_t n_chunks = (uint32_t)cnt;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t c = wave_id; c < n_chunks; c += n_waves) {
-        uint32_t lo = 0, hi = n_hits;                // last hit with chunk_base <= c
+    // a wave takes a CONTIGUOUS run of chunks: one binary search for the hit of its first chunk, a walk along the list for the
+    // others (chunk numbers ascend with the hits) -- a fresh search per chunk was fifteen dependent loads each
+    const uint32_t per_wave = (n_chunks + n_waves - 1) / n_waves;
+    const uint32_t c_first = wave_id * per_wave, c_end = c_first + per_wave < n_chunks ? c_first + per_wave : n_chunks;
+    uint32_t lo = 0;
+    if (c_first < c_end) {
+        uint32_t hi = n_hits;                        // last hit with chunk_base <= c_first
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (hits[mid].chunk_base <= c) lo = mid; else hi = mid;
+            if (hits[mid].chunk_base <= c_first) lo = mid; else hi = mid;
         }
+    }
+    for (uint32_t c = c_first; c < c_end; ++c) {
+        while (lo + 1 < n_hits && hits[lo + 1].chunk_base <= c) ++lo;
         const KwHit h = hits[lo];
         if (skip_term && skip_term[h.term]) continue;   // the term's bitmap is a stored token bitmap: nothing to expand
         const uint64_t post_end = h.post_begin + h.post_len;
