@@ -1850,8 +1850,10 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
         const size_t off_lk = off_match8 + sizeof(orr::MatchTerm8) * TT;       // [8 u32 class boundaries][TT keys][TT term numbers]
         const size_t off_pool = off_lk + sizeof(uint32_t) * (8 + 2 * (size_t)TT);
         const size_t off_bloom = (off_pool + pool_bytes + 16 + 15) / 16 * 16;   // (last: only uploaded when the lookup form runs)
+        // (the lookup pays from tens of millions of (token, term) pairs on: below, sorting the terms on the host -- 0.15 ms for the
+        // 3,000 terms of 1024 queries -- costs more than comparing them all on the GPU)
         const bool vocab_lookup = [&] { static const int e = [] { const char *v = getenv("ORR_VOCAB_LOOKUP"); return v ? atoi(v) : -1; }();
-                                        return e >= 0 ? e != 0 : TT >= 64; }();
+                                        return e >= 0 ? e != 0 : (TT >= 64 && (int64_t)TT * idx->n_tokens >= ((int64_t)1 << 25)); }();
         const size_t meta_bytes = vocab_lookup ? off_bloom + orr::kVocabBloomBits / 8 : off_pool + pool_bytes + 16;
         ORR_TRY(idx->pin_meta.reserve(meta_bytes));
         ORR_TRY(idx->ws_meta.reserve(meta_bytes));
@@ -1885,7 +1887,7 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
             memcpy(hm + off_pool + cursor, dterms[t].data(), dterms[t].size());
             cursor += st[t].len;
         }
-        {   // the terms of at most 16 bytes sorted by (class = min(bytes, 4), length-masked first dword): vocab_match_lookup
+        if (vocab_lookup) {   // the terms of at most 16 bytes sorted by (class = min(bytes, 4), length-masked first dword): vocab_match_lookup
             uint32_t *lk = reinterpret_cast<uint32_t *>(hm + off_lk), *keys = lk + 8, *tix = keys + TT;
             const orr::MatchTerm *mts = reinterpret_cast<const orr::MatchTerm *>(hm + off_match);
             std::vector<std::pair<uint64_t, uint32_t>> order;
@@ -1902,13 +1904,11 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
             }
             for (int c = 1; c <= 4; ++c) lk[c] = std::max(lk[c], lk[c - 1]);     // empty classes inherit the boundary in front of them
             lk[5] = lk[6] = lk[7] = 0;
-            if (vocab_lookup) {
-                uint32_t *bloom = reinterpret_cast<uint32_t *>(hm + off_bloom);
-                memset(bloom, 0, orr::kVocabBloomBits / 8);
-                for (const auto &o : order) {
-                    const uint32_t hb = orr::vocab_bloom_hash((uint32_t)o.first, (uint32_t)(o.first >> 32));
-                    bloom[hb >> 5] |= 1u << (hb & 31u);
-                }
+            uint32_t *bloom = reinterpret_cast<uint32_t *>(hm + off_bloom);
+            memset(bloom, 0, orr::kVocabBloomBits / 8);
+            for (const auto &o : order) {
+                const uint32_t hb = orr::vocab_bloom_hash((uint32_t)o.first, (uint32_t)(o.first >> 32));
+                bloom[hb >> 5] |= 1u << (hb & 31u);
             }
         }
         memcpy(hm + off_qmeta, qmeta.data(), sizeof(uint32_t) * qmeta.size());
@@ -1957,8 +1957,8 @@ int launch_keyword_side(orr_index *idx, const BatchArgs &a, const std::vector<ui
         };
         if (V > 0) {
             const orr::ScanTerm *d_terms = reinterpret_cast<const orr::ScanTerm *>(dm + off_terms);
-            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place; from 64 terms
-                // on the terms are looked up (sorted by first dword) instead of compared one by one (ORR_VOCAB_LOOKUP=0|1 forces either)
+            {   // tokens of at most 16 bytes: one lane per token against every distinct term, hits reserved in place; where tokens x terms
+                // is large the terms are looked up (sorted by first dword) instead of compared one by one (ORR_VOCAB_LOOKUP=0|1 forces either)
                 Timed t(idx, "vocab_match", 0.0, k);
                 if (vocab_lookup) {
                     const uint32_t *lk = reinterpret_cast<const uint32_t *>(dm + off_lk);
